@@ -1,0 +1,723 @@
+/*
+ * rvo3d_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * Scalar fp64 restatement of the reference step, written to follow the
+ * reference's evaluation order operation by operation.  Every function cites
+ * the reference file:line it restates (paths relative to the reference root).
+ *
+ * Arithmetic model of the reference's numpy/libm calls, measured in the build
+ * container (numpy 2.2.6 + scipy-openblas 0.3.29, glibc libm):
+ *   x ** 2                 -> pow(x, 2.0)            (python float and np.float64)
+ *   np.dot / np.linalg.norm on 2/3-vectors
+ *                          -> fma chain  fma(z,z, fma(y,y, x*x))   (OpenBLAS ddot tail)
+ *   np.sin / np.cos        -> glibc sin / cos (bit-identical on 200k samples)
+ *   np.arccos/arctan2/exp/log -> numpy SIMD kernels, <= 1 ulp from glibc in
+ *                          0.1-9 % of calls; this file uses glibc.  Every value
+ *                          they feed is rounded to 2-3 decimals before it is
+ *                          observable, see DESIGN.md "ulp budget".
+ * Compile with -ffp-contract=off: the only fused operations are the explicit
+ * fma() calls.
+ */
+#define _GNU_SOURCE
+#include "rvo3d_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define GOAL_THRESHOLD 0.4   /* drone.py:15  goal_threshold            */
+#define NEIGHBOR_GATE 10.0   /* rvo_inter.py:96 literal                */
+#define BUILDING_GATE 5.0    /* rvo_inter.py:104 literal               */
+#define CTIME_THRESHOLD 2.0  /* rvo_inter.py:11 ctime_threshold        */
+#define EXP_RADIUS 0.2       /* rvo_inter.py:11 exp_radius             */
+#define MAX_ACC 1.0          /* drone.py:72                            */
+#define MAX_ANGLE 90.0       /* drone.py:73                            */
+#define DEG2RAD 0.017453292519943295 /* np.deg2rad: x * (pi/180)       */
+
+struct orc_env {
+  int E, N, P, nb, nm, env_train, threads;
+  double map[3];
+  /* static world */
+  double *wp;        /* [E*N][P][3] */
+  int32_t *n_points; /* [E*N] */
+  double *route_len; /* [E*N]   drone.py:31 */
+  double *radius, *prio;
+  double *bld;       /* [nb][4] */
+  /* mutable state, drone.py:14-82 */
+  double *p, *v;     /* [E*N][3] */
+  double *yaw, *pitch, *real_len, *max_dev, *extra_len;
+  int32_t *wp_idx;
+  uint8_t *arrive, *dest;
+  int64_t nan_count;
+};
+
+/* ---- arithmetic primitives ------------------------------------------- */
+#ifndef ORC_VARIANT
+static inline double sq(double x) { return pow(x, 2.0); }
+static inline double dot3_blas(const double *a, const double *b) {
+  return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0]));
+}
+static inline double norm2_blas(double x, double y) { return sqrt(fma(y, y, x * x)); }
+#else
+/* ulp-perturbed variant, used only by gen_golden.py's margin audit: a fixture
+ * whose outputs change under this arithmetic sits on a decision boundary. */
+static inline double sq(double x) { return x * x; }
+static inline double dot3_blas(const double *a, const double *b) {
+  return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+static inline double norm2_blas(double x, double y) { return sqrt(x * x + y * y); }
+#endif
+static inline double norm3_blas(const double *a) { return sqrt(dot3_blas(a, a)); }
+
+double orc_np_round(double x, int decimals) {
+  /* numpy round: multiply, rint, true_divide */
+  double f = decimals == 2 ? 100.0 : (decimals == 3 ? 1000.0 : pow(10.0, decimals));
+  return rint(x * f) / f;
+}
+static inline double np_round2(double x) { return rint(x * 100.0) / 100.0; }
+static inline double np_round3(double x) { return rint(x * 1000.0) / 1000.0; }
+
+double orc_py_round2(double x) {
+  /* Python float round(x, 2): correctly rounded decimal of the exact binary
+   * value, ties to even, then nearest double (floatobject.c double_round). */
+  if (!isfinite(x)) return x;
+  double p = x * 100.0;
+  double e = fma(x, 100.0, -p); /* exact: x*100 = p + e */
+  double c = floor(p);
+  double d = (p - (c + 0.5)) + e;
+  if (d > 0.0) c += 1.0;
+  else if (d == 0.0 && fmod(c, 2.0) != 0.0) c += 1.0;
+  return c / 100.0;
+}
+
+/* ---- drone.py helpers -------------------------------------------------- */
+typedef struct {
+  double s[12]; /* x y z vx vy vz r prio dvx dvy dvz deviation (drone.py:263) */
+} dstate;
+
+static inline const double *wp_at(const orc_env *h, int g, int k) {
+  return h->wp + ((size_t)g * h->P + k) * 3;
+}
+
+/* drone.cal_des_vel + relative + angles_to_direction
+ * (drone.py:199-210, 340-352, 319-328) */
+static void cal_des_vel(const double *p, const double *cur_des, double *out) {
+  double dif[3] = {cur_des[0] - p[0], cur_des[1] - p[1], cur_des[2] - p[2]};
+  double dis = norm3_blas(dif);
+  double az = atan2(dif[1], dif[0]);
+  double el = (dis != 0.0) ? atan2(dif[2], norm2_blas(dif[0], dif[1])) : 0.0;
+  if (dis > GOAL_THRESHOLD) {
+    double dir[3] = {cos(az) * cos(el), sin(az) * cos(el), sin(el)};
+    for (int k = 0; k < 3; ++k) out[k] = np_round3(1.0 * dir[k]);
+  } else {
+    out[0] = out[1] = out[2] = 0.0;
+  }
+}
+
+/* drone.calculate_deviation (drone.py:366-406): distance to the infinite line */
+static double calc_deviation(const double *a, const double *b, const double *p) {
+  double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+  double mag = sqrt(sq(dx) + sq(dy) + sq(dz));
+  if (mag == 0.0) return 0.0;
+  double hx = dx / mag, hy = dy / mag, hz = dz / mag;
+  double px = p[0] - a[0], py = p[1] - a[1], pz = p[2] - a[2];
+  double t = px * hx + py * hy + pz * hz;
+  double qx = a[0] + t * hx, qy = a[1] + t * hy, qz = a[2] + t * hz;
+  return sqrt(sq(p[0] - qx) + sq(p[1] - qy) + sq(p[2] - qz));
+}
+
+static inline void cur_prev_des(const orc_env *h, int g, const double **cur,
+                                const double **prev) {
+  int i = h->wp_idx[g];
+  *cur = wp_at(h, g, i);
+  *prev = wp_at(h, g, i - 1);
+}
+
+/* drone.dronestate (drone.py:254-263), incl. the max_deviation side effect */
+static void dronestate(orc_env *h, int g, dstate *o) {
+  const double *cur, *prev;
+  cur_prev_des(h, g, &cur, &prev);
+  const double *p = h->p + 3 * (size_t)g, *v = h->v + 3 * (size_t)g;
+  o->s[0] = p[0]; o->s[1] = p[1]; o->s[2] = p[2];
+  o->s[3] = v[0]; o->s[4] = v[1]; o->s[5] = v[2];
+  o->s[6] = h->radius[g];
+  o->s[7] = h->prio[g];
+  cal_des_vel(p, cur, &o->s[8]);
+  double dev = calc_deviation(prev, cur, p);
+  if (dev > h->max_dev[g]) h->max_dev[g] = dev;
+  o->s[11] = dev;
+}
+
+static inline int arrive(const double *p, const double *des) {
+  double d[3] = {p[0] - des[0], p[1] - des[1], p[2] - des[2]};
+  return norm3_blas(d) <= GOAL_THRESHOLD; /* drone.py:172-179 */
+}
+/* drone.destination_arrive (drone.py:182-192): side effect on extra_len */
+static inline int destination_arrive(orc_env *h, int g) {
+  const double *dst = wp_at(h, g, h->n_points[g] - 1);
+  if (arrive(h->p + 3 * (size_t)g, dst)) {
+    h->extra_len[g] = h->real_len[g] - h->route_len[g];
+    return 1;
+  }
+  return 0;
+}
+
+/* numpy float remainder (npy_divmod), used by `% 360` at drone.py:457 */
+static inline double np_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0.0) != (m < 0.0)) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m;
+}
+static inline double clampd(double x, double lo, double hi) {
+  return x < lo ? lo : (x > hi ? hi : x); /* np.clip */
+}
+
+/* env_base.drone_step -> drone.move_forward (env_base.py:135-144,
+ * drone.py:96-129), with kinematicstep (drone.py:435-490).  `stop` receives
+ * map_size (truthy) because of the argument shift at env_base.py:142. */
+static void move_forward(orc_env *h, int g, const double *act) {
+  double *p = h->p + 3 * (size_t)g, *v = h->v + 3 * (size_t)g;
+  double speed = norm3_blas(v);                           /* drone.py:103 */
+  double acc = clampd(act[0] * MAX_ACC, -MAX_ACC, MAX_ACC);
+  double dyaw = clampd(act[1] * MAX_ANGLE, -MAX_ANGLE, MAX_ANGLE);
+  double dpit = clampd(act[2] * MAX_ANGLE, -MAX_ANGLE, MAX_ANGLE);
+  double nv = speed + acc * 1;
+  speed = (0.0 > nv) ? 0.0 : nv;                          /* python max(nv, 0), drone.py:452 */
+  h->yaw[g] = np_mod(h->yaw[g] + dyaw, 360.0);
+  h->pitch[g] = clampd(h->pitch[g] + dpit, -90.0, 90.0);
+  double yr = h->yaw[g] * DEG2RAD, pr = h->pitch[g] * DEG2RAD;
+  double vel[3] = {speed * cos(pr) * cos(yr), speed * cos(pr) * sin(yr),
+                   speed * sin(pr)};
+  if (h->dest[g]) vel[0] = vel[1] = vel[2] = 0.0;         /* drone.py:107-109 */
+  double prev[3] = {p[0], p[1], p[2]};
+  for (int k = 0; k < 3; ++k) {
+    p[k] = p[k] + vel[k] * 1;                             /* drone.py:167, dt = 1 */
+    v[k] = vel[k];
+  }
+  double d[3] = {p[0] - prev[0], p[1] - prev[1], p[2] - prev[2]};
+  h->real_len[g] = h->real_len[g] + norm3_blas(d);       /* drone.py:86-90 */
+  const double *cur = wp_at(h, g, h->wp_idx[g]);
+  if (arrive(p, cur) && !destination_arrive(h, g)) {      /* drone.py:116 */
+    if (h->wp_idx[g] < h->n_points[g] - 1) {              /* drone.py:117,123 */
+      h->wp_idx[g] += 1;
+      h->arrive[g] = 0;
+    }
+  }
+}
+
+/* ---- vel_obs ---------------------------------------------------------- */
+typedef struct {
+  double obs[9]; /* PAA(3) rel(3) alpha min_dis iet */
+  int flag, collision;
+  double t, min_dis;
+} vo_inf;
+
+/* vel_obs3D.cal_vo_exp_tim (vel_obs3D.py:145-182) */
+static double cal_vo_exp_tim(double rx, double ry, double rz, double rvx,
+                             double rvy, double rvz, double ra, double rb) {
+  double r = ra + rb;
+  double ux = -rvx, uy = -rvy, uz = -rvz;
+  double a = sq(ux) + sq(uy) + sq(uz);
+  double b = 2 * rx * ux + 2 * ry * uy + 2 * rz * uz;
+  double c = sq(rx) + sq(ry) + sq(rz) - sq(r);
+  if (c <= 0) return 0.0;
+  double temp = sq(b) - 4 * a * c;
+  if (temp <= 0) return INFINITY;
+  double t1 = (-b + sqrt(temp)) / (2 * a);
+  double t2 = (-b - sqrt(temp)) / (2 * a);
+  if (t1 < 0 && t2 < 0) return -1.0;
+  double t3 = t1 >= 0 ? t1 : INFINITY;
+  double t4 = t2 >= 0 ? t2 : INFINITY;
+  return t3 < t4 ? t3 : t4; /* python min(t3, t4): first arg wins ties / NaN */
+}
+
+/* rvo_inter.config_vo_circle2 (rvo_inter.py:116-196) with get_alpha,
+ * get_PAA, vo_out_jud_vector, get_beta (vel_obs3D.py:8-66, rvo_inter.py:212-228) */
+static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O,
+                              const double *action_in, vo_inf *out) {
+  double action[3] = {action_in[0], action_in[1], action_in[2]};
+  if (norm3_blas(action) < 1e-5) action[0] = action[1] = action[2] = 0.0;
+  const double x = S->s[0], y = S->s[1], z = S->s[2];
+  const double vx = S->s[3], vy = S->s[4], vz = S->s[5], r = S->s[6];
+  const double mx = O->s[0], my = O->s[1], mz = O->s[2];
+  const double mvx = O->s[3], mvy = O->s[4], mvz = O->s[5], mr = O->s[6];
+  double rel[3] = {mx - x, my - y, mz - z};
+  double dis = sqrt(sq(rel[1]) + sq(rel[0]) + sq(rel[2]));
+  double real_dis = dis;
+  int collision = 0;
+  if (h->env_train) {
+    if (dis <= r + mr) { dis = r + mr; collision = 1; }
+  } else {
+    if (dis <= r - EXP_RADIUS + mr) collision = 1;
+    if (dis <= r + mr) dis = r + mr;
+  }
+  out->flag = 0;
+  out->collision = collision;
+  out->t = 0.0;
+  out->min_dis = dis;
+  if (collision) return;                                   /* rvo_inter.py:152 */
+  double dotp = vx * rel[0] + vy * rel[1] + vz * rel[2];
+  if (dotp <= 0) return;                                   /* rvo_inter.py:159 */
+
+  /* get_alpha */
+  double ab[3] = {mx - x, my - y, mz - z};
+  double alpha = orc_py_round2(asin((r + mr) / norm3_blas(ab)));
+  /* get_PAA */
+  double pr = S->s[7] / (S->s[7] + O->s[7]);
+  double paa[3] = {pr * (2 * x + (vx + mvx) * 1), pr * (2 * y + (vy + mvy) * 1),
+                   pr * (2 * z + (vz + mvz) * 1)};
+  double rvx = 2 * action[0] - mvx - vx;
+  double rvy = 2 * action[1] - mvy - vy;
+  double rvz = 2 * action[2] - mvz - vz;
+  /* vo_out_jud_vector + get_beta */
+  double w[3] = {(x + 2 * action[0] * 1) - paa[0], (y + 2 * action[1] * 1) - paa[1],
+                 (z + 2 * action[2] * 1) - paa[2]};
+  double dp = dot3_blas(rel, w);
+  double AB = norm3_blas(rel) * norm3_blas(w);
+  double cosang = (AB != 0) ? dp / AB : 0.0;
+  double beta = np_round2(acos(cosang)); /* NaN when |cos| > 1, as np.arccos */
+  double t = INFINITY;
+  int flag = 0;
+  if (alpha > beta) { /* inside the cone */
+    t = cal_vo_exp_tim(rel[0], rel[1], rel[2], rvx, rvy, rvz, r, mr);
+    if (t < CTIME_THRESHOLD) flag = 1;
+    else t = INFINITY;
+  }
+  double iet = 1 / (t + 0.2);
+  double min_dis = real_dis - mr;
+  out->obs[0] = paa[0]; out->obs[1] = paa[1]; out->obs[2] = paa[2];
+  out->obs[3] = rel[0]; out->obs[4] = rel[1]; out->obs[5] = rel[2];
+  out->obs[6] = alpha; out->obs[7] = min_dis; out->obs[8] = iet;
+  out->flag = flag;
+  out->t = t;
+  out->min_dis = min_dis;
+}
+
+/* neighbour gate of rvo_inter.preprocess (rvo_inter.py:90-97) */
+static inline int in_gate(const dstate *S, const dstate *O) {
+  if (S->s[0] == O->s[0] && S->s[1] == O->s[1] && S->s[2] == O->s[2]) return 0;
+  double dif[3] = {S->s[0] - O->s[0], S->s[1] - O->s[1], S->s[2] - O->s[2]};
+  return norm3_blas(dif) <= NEIGHBOR_GATE;
+}
+
+/* building gate (rvo_inter.py:99-105) + check_col_with_budilding (:198-209) */
+static int building_collision(const orc_env *h, const dstate *S) {
+  int hit = 0;
+  for (int b = 0; b < h->nb; ++b) {
+    const double *B = h->bld + 4 * b;
+    if (B[2] > S->s[2] - 2) {
+      if (norm2_blas(S->s[0] - B[0], S->s[1] - B[1]) <= BUILDING_GATE) {
+        if (S->s[2] <= B[2]) {
+          double dis = sqrt(sq(S->s[0] - B[0]) + sq(S->s[1] - B[1]));
+          if (dis <= S->s[6] + B[3]) hit = 1;
+        }
+      }
+    }
+  }
+  return hit;
+}
+
+/* rvo_inter.config_vo_reward (rvo_inter.py:63-83) */
+static void config_vo_reward(const orc_env *h, const dstate *all, int i,
+                             const double *action, int *vo_flag, double *tmin) {
+  *vo_flag = 0;
+  *tmin = INFINITY;
+  for (int j = 0; j < h->N; ++j) {
+    if (j == i || !in_gate(&all[i], &all[j])) continue;
+    vo_inf v;
+    config_vo_circle2(h, &all[i], &all[j], action, &v);
+    if (v.flag) {
+      *vo_flag = 1;
+      if (v.t < *tmin) *tmin = v.t;
+    }
+  }
+}
+
+/* rvo_inter.config_vo_inf (rvo_inter.py:20-61).  out rows are written in the
+ * reference's final order (ascending urgency, most urgent last). */
+typedef struct { double iet, md; int j; double obs[9]; } vo_row;
+
+static int row_before(const vo_row *a, const vo_row *b) {
+  /* a precedes b in list.sort(reverse=True, key=(-iet, min_dis)) (stable) */
+  if (-a->iet != -b->iet) return -a->iet > -b->iet;
+  if (a->md != b->md) return a->md > b->md;
+  return a->j < b->j;
+}
+
+static void config_vo_inf(const orc_env *h, const dstate *all, int i,
+                          const double *action, vo_row *scratch, double *rows,
+                          int *count, int *vo_flag, double *tmin, int *collision) {
+  int k = 0;
+  *vo_flag = 0;
+  *tmin = INFINITY;
+  *collision = building_collision(h, &all[i]);
+  for (int j = 0; j < h->N; ++j) {
+    if (j == i || !in_gate(&all[i], &all[j])) continue;
+    vo_inf v;
+    config_vo_circle2(h, &all[i], &all[j], action, &v);
+    if (v.flag) {
+      scratch[k].iet = v.obs[8];
+      scratch[k].md = v.obs[7];
+      scratch[k].j = j;
+      memcpy(scratch[k].obs, v.obs, sizeof v.obs);
+      ++k;
+      *vo_flag = 1;
+      if (v.t < *tmin) *tmin = v.t;
+    }
+    if (v.collision) *collision = 1;
+  }
+  /* stable insertion sort into the reference order */
+  for (int a = 1; a < k; ++a) {
+    vo_row tmp = scratch[a];
+    int b = a - 1;
+    while (b >= 0 && row_before(&tmp, &scratch[b])) { scratch[b + 1] = scratch[b]; --b; }
+    scratch[b + 1] = tmp;
+  }
+  int keep = k > h->nm ? h->nm : k; /* keep the LAST nm (rvo_inter.py:53-59) */
+  int first = k - keep;
+  for (int a = 0; a < keep; ++a) memcpy(rows + 9 * a, scratch[first + a].obs, 9 * sizeof(double));
+  *count = keep;
+}
+
+/* ---- ir_gym rewards ---------------------------------------------------- */
+/* ir_gym.rvo_reward_cal (ir_gym.py:64-133) with the second
+ * calculate_angle_between_vectors (ir_gym.py:447-473) */
+static double rvo_reward_cal(const orc_env *h, const dstate *all, int i,
+                             const double *action) {
+  int vo_flag; double tmin;
+  config_vo_reward(h, all, i, action, &vo_flag, &tmin);
+  double des[3] = {np_round3(all[i].s[8]), np_round3(all[i].s[9]), np_round3(all[i].s[10])};
+  double vel_penalty = 0.2 * norm3_blas(action) / norm3_blas(des);
+  const double eps = 1e-8;
+  double magA = sqrt(sq(des[0]) + sq(des[1]) + sq(des[2]) + eps);
+  double magB = sqrt(sq(action[0]) + sq(action[1]) + sq(action[2]) + eps);
+  double dotp = des[0] * action[0] + des[1] * action[1] + des[2] * action[2];
+  double ang;
+  if (magA < 1e-6 || magB < 1e-6) ang = 0.0;
+  else {
+    double c = dotp / (magA * magB);
+    c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c); /* np.clip */
+    ang = acos(c);
+  }
+  double angle_punish;
+  if (-M_PI / 18 < ang && ang < M_PI / 18) angle_punish = 3;
+  else if (-M_PI / 6 < ang && ang < M_PI / 6) angle_punish = 1;
+  else if (-M_PI / 3 < ang && ang < M_PI / 3) angle_punish = 0.5;
+  else if (-M_PI / 2 < ang && ang < M_PI / 2) angle_punish = 0;
+  else angle_punish = -4;
+  double safety = 0;
+  if (vo_flag) {
+    double urgency = 0;
+    if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
+    safety = -2.5 + urgency;
+  }
+  return np_round3(angle_punish + vel_penalty + safety);
+}
+
+/* ir_gym.mov_reward + calculate_penalty_with_exp (ir_gym.py:256-311, 476-490) */
+static double mov_reward(int collision, int arrive_reward, int waypoint_num,
+                         int n_points, int dest_reward, double deviation,
+                         int len_flag, double exlen) {
+  if (collision) return -50;
+  double reward = 0;
+  if (arrive_reward) reward += 3.0 * pow(0.95, (double)(n_points - waypoint_num));
+  if (dest_reward) reward += 20.0;
+  double d = deviation * 10;
+  double dev_penalty = -1.5 * (2 / (1 + exp(-(d - 5) / 0.3)));
+  double exlen_penalty = 0;
+  if (len_flag) {
+    exlen_penalty = -0.3 * log(exlen + 1 + 1e-6);
+    if (exlen_penalty < -6 || exlen_penalty != exlen_penalty) exlen_penalty = -6;
+  }
+  return np_round3(reward + dev_penalty + exlen_penalty);
+}
+
+static int out_of_map(const orc_env *h, const double *p) { /* drone.py:213-225 */
+  return p[0] < 0 || p[0] > h->map[0] || p[1] < 0 || p[1] > h->map[1] ||
+         p[2] < 0 || p[2] > h->map[2];
+}
+
+static void write_obs(orc_env *h, const dstate *S, const double *rows, int count,
+                      double *obs) {
+  int W = 12 + 9 * h->nm, bad = 0;
+  for (int k = 0; k < 12; ++k) obs[k] = np_round2(S->s[k]);
+  for (int k = 0; k < 9 * count; ++k) obs[12 + k] = np_round2(rows[k]);
+  for (int k = 12 + 9 * count; k < W; ++k) obs[k] = 0.0;
+  for (int k = 0; k < W; ++k) if (!isfinite(obs[k])) bad = 1;
+  if (bad) {
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+    h->nan_count += 1;
+  }
+}
+
+/* ---- per-env drivers ---------------------------------------------------- */
+typedef struct { dstate *st; vo_row *scratch; double *rows; } work;
+
+static void env_observe(orc_env *h, int e, work *w, double *obs, int32_t *vo_count) {
+  /* ir_gym.observation / env_observation (ir_gym.py:334-383): action = 0 */
+  const int N = h->N, W = 12 + 9 * h->nm;
+  const double zero[3] = {0, 0, 0};
+  for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
+  for (int i = 0; i < N; ++i) {
+    int cnt, vf, col; double tmin;
+    config_vo_inf(h, w->st, i, zero, w->scratch, w->rows, &cnt, &vf, &tmin, &col);
+    write_obs(h, &w->st[i], w->rows, cnt, obs + (size_t)(e * N + i) * W);
+    vo_count[e * N + i] = cnt;
+  }
+}
+
+static void env_step(orc_env *h, int e, work *w, const double *actions, double *obs,
+                     int32_t *vo_count, double *reward, uint8_t *done,
+                     uint8_t *info, uint8_t *finish) {
+  const int N = h->N, W = 12 + 9 * h->nm;
+  /* sweep A: ir_gym.rvo_reward_list_cal (ir_gym.py:50-62) on pre-move states */
+  for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
+  for (int i = 0; i < N; ++i)
+    reward[e * N + i] = rvo_reward_cal(h, w->st, i, actions + 3 * (size_t)(e * N + i));
+  /* integrate: env_base.drone_step (env_base.py:135-144) */
+  for (int i = 0; i < N; ++i) move_forward(h, e * N + i, actions + 3 * (size_t)(e * N + i));
+  /* sweep B: ir_gym.obs_move_reward_list / observation_reward (ir_gym.py:136-254) */
+  for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
+  for (int i = 0; i < N; ++i) {
+    const int g = e * N + i;
+    const double *p = h->p + 3 * (size_t)g;
+    int arrive_reward = 0, dest_reward = 0;
+    int waypoint_num = h->wp_idx[g];
+    int n_points = h->n_points[g] - 1;
+    if (arrive(p, wp_at(h, g, h->wp_idx[g])) && !h->arrive[g]) {
+      h->arrive[g] = 1;
+      arrive_reward = 1;
+    }
+    if (h->arrive[g]) {
+      if (destination_arrive(h, g) && !h->dest[g]) {
+        h->dest[g] = 1;
+        dest_reward = 1;
+      }
+    }
+    double deviation = w->st[i].s[11];
+    double exlen = h->real_len[g] - h->route_len[g] + 4;
+    int len_flag = exlen > 0;
+    int cnt, vf, col; double tmin;
+    config_vo_inf(h, w->st, i, actions + 3 * (size_t)g, w->scratch, w->rows, &cnt,
+                  &vf, &tmin, &col);
+    if (out_of_map(h, p)) col = 1;
+    write_obs(h, &w->st[i], w->rows, cnt, obs + (size_t)g * W);
+    vo_count[g] = cnt;
+    double mr = mov_reward(col, arrive_reward, waypoint_num, n_points, dest_reward,
+                           deviation, len_flag, exlen);
+    reward[g] = reward[g] + mr;                            /* mdin.py:28 */
+    done[g] = (uint8_t)col;
+    info[g] = h->arrive[g];
+    finish[g] = h->dest[g];
+  }
+}
+
+static void reset_drone(orc_env *h, int g) { /* drone.reset, drone.py:270-291 */
+  const double *s = wp_at(h, g, 0);
+  for (int k = 0; k < 3; ++k) { h->p[3 * (size_t)g + k] = s[k]; h->v[3 * (size_t)g + k] = 0.0; }
+  h->wp_idx[g] = 1;
+  h->arrive[g] = 0;
+  h->dest[g] = 0;
+  h->real_len[g] = 0.0;
+  h->max_dev[g] = 0.0;
+  h->yaw[g] = 0.0;
+  h->pitch[g] = 0.0;
+  /* extra_len is NOT cleared by the reference's reset */
+}
+
+/* ---- public API --------------------------------------------------------- */
+orc_env *orc_create(int E, int N, int P, int nb, int nm, int env_train,
+                    const double *map_size) {
+  if (E < 1 || N < 1 || P < 2 || nb < 0 || nm < 0) return NULL;
+  orc_env *h = (orc_env *)calloc(1, sizeof *h);
+  size_t G = (size_t)E * N;
+  h->E = E; h->N = N; h->P = P; h->nb = nb; h->nm = nm; h->env_train = env_train;
+  h->threads = 1;
+  memcpy(h->map, map_size, sizeof h->map);
+  h->wp = (double *)calloc(G * P * 3, sizeof(double));
+  h->n_points = (int32_t *)calloc(G, sizeof(int32_t));
+  h->route_len = (double *)calloc(G, sizeof(double));
+  h->radius = (double *)calloc(G, sizeof(double));
+  h->prio = (double *)calloc(G, sizeof(double));
+  h->bld = (double *)calloc((size_t)(nb > 0 ? nb : 1) * 4, sizeof(double));
+  h->p = (double *)calloc(G * 3, sizeof(double));
+  h->v = (double *)calloc(G * 3, sizeof(double));
+  h->yaw = (double *)calloc(G, sizeof(double));
+  h->pitch = (double *)calloc(G, sizeof(double));
+  h->real_len = (double *)calloc(G, sizeof(double));
+  h->max_dev = (double *)calloc(G, sizeof(double));
+  h->extra_len = (double *)calloc(G, sizeof(double));
+  h->wp_idx = (int32_t *)calloc(G, sizeof(int32_t));
+  h->arrive = (uint8_t *)calloc(G, 1);
+  h->dest = (uint8_t *)calloc(G, 1);
+  return h;
+}
+
+void orc_destroy(orc_env *h) {
+  if (!h) return;
+  free(h->wp); free(h->n_points); free(h->route_len); free(h->radius); free(h->prio);
+  free(h->bld); free(h->p); free(h->v); free(h->yaw); free(h->pitch);
+  free(h->real_len); free(h->max_dev); free(h->extra_len); free(h->wp_idx);
+  free(h->arrive); free(h->dest); free(h);
+}
+
+void orc_load_world(orc_env *h, const double *waypoints, const int32_t *n_points,
+                    const double *buildings, const double *radius,
+                    const double *priority) {
+  size_t G = (size_t)h->E * h->N;
+  memcpy(h->wp, waypoints, G * h->P * 3 * sizeof(double));
+  memcpy(h->n_points, n_points, G * sizeof(int32_t));
+  if (h->nb > 0) memcpy(h->bld, buildings, (size_t)h->nb * 4 * sizeof(double));
+  for (size_t g = 0; g < G; ++g) {
+    h->radius[g] = radius ? radius[g] : 0.2;
+    h->prio[g] = priority ? priority[g] : 5.0;
+    /* drone.calculate_total_length (drone.py:409-429) */
+    double total = 0.0;
+    for (int k = 0; k + 1 < h->n_points[g]; ++k) {
+      const double *a = wp_at(h, (int)g, k), *b = wp_at(h, (int)g, k + 1);
+      total += sqrt(sq(b[0] - a[0]) + sq(b[1] - a[1]) + sq(b[2] - a[2]));
+    }
+    h->route_len[g] = total;
+    h->extra_len[g] = 0.0;
+    reset_drone(h, (int)g);
+  }
+}
+
+void orc_reset(orc_env *h, const uint8_t *env_mask) {
+  for (int e = 0; e < h->E; ++e)
+    if (!env_mask || env_mask[e])
+      for (int i = 0; i < h->N; ++i) reset_drone(h, e * h->N + i);
+}
+
+void orc_reset_drones(orc_env *h, const uint8_t *mask) {
+  for (int g = 0; g < h->E * h->N; ++g)
+    if (mask[g]) reset_drone(h, g);
+}
+
+static work *work_alloc(const orc_env *h) {
+  work *w = (work *)malloc(sizeof *w);
+  w->st = (dstate *)malloc(sizeof(dstate) * h->N);
+  w->scratch = (vo_row *)malloc(sizeof(vo_row) * h->N);
+  w->rows = (double *)malloc(sizeof(double) * 9 * (h->nm > 0 ? h->nm : 1));
+  return w;
+}
+static void work_free(work *w) { free(w->st); free(w->scratch); free(w->rows); free(w); }
+
+void orc_observe(orc_env *h, double *obs, int32_t *vo_count) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(h->threads)
+#endif
+  {
+    work *w = work_alloc(h);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int e = 0; e < h->E; ++e) env_observe(h, e, w, obs, vo_count);
+    work_free(w);
+  }
+}
+
+void orc_step(orc_env *h, const double *actions, double *obs, int32_t *vo_count,
+              double *reward, uint8_t *done, uint8_t *info, uint8_t *finish) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(h->threads)
+#endif
+  {
+    work *w = work_alloc(h);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int e = 0; e < h->E; ++e)
+      env_step(h, e, w, actions, obs, vo_count, reward, done, info, finish);
+    work_free(w);
+  }
+}
+
+void orc_step_autoreset(orc_env *h, const double *actions, double *obs,
+                        int32_t *vo_count, double *reward, uint8_t *done,
+                        uint8_t *info, uint8_t *finish, uint8_t *reset_mask) {
+#ifdef _OPENMP
+#pragma omp parallel num_threads(h->threads)
+#endif
+  {
+    work *w = work_alloc(h);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int e = 0; e < h->E; ++e) {
+      env_step(h, e, w, actions, obs, vo_count, reward, done, info, finish);
+      int any = 0;
+      for (int i = 0; i < h->N; ++i) {
+        int g = e * h->N + i;
+        int r = done[g] || finish[g];
+        if (reset_mask) reset_mask[g] = (uint8_t)r;
+        if (r) { reset_drone(h, g); any = 1; }
+      }
+      if (any) env_observe(h, e, w, obs, vo_count);
+    }
+    work_free(w);
+  }
+}
+
+void orc_get_state(const orc_env *h, double *pos, double *vel, double *yaw,
+                   double *pitch, double *real_len, double *max_dev,
+                   double *extra_len, int32_t *wp_idx, uint8_t *arrive_f,
+                   uint8_t *dest) {
+  size_t G = (size_t)h->E * h->N;
+  if (pos) memcpy(pos, h->p, G * 3 * sizeof(double));
+  if (vel) memcpy(vel, h->v, G * 3 * sizeof(double));
+  if (yaw) memcpy(yaw, h->yaw, G * sizeof(double));
+  if (pitch) memcpy(pitch, h->pitch, G * sizeof(double));
+  if (real_len) memcpy(real_len, h->real_len, G * sizeof(double));
+  if (max_dev) memcpy(max_dev, h->max_dev, G * sizeof(double));
+  if (extra_len) memcpy(extra_len, h->extra_len, G * sizeof(double));
+  if (wp_idx) memcpy(wp_idx, h->wp_idx, G * sizeof(int32_t));
+  if (arrive_f) memcpy(arrive_f, h->arrive, G);
+  if (dest) memcpy(dest, h->dest, G);
+}
+
+void orc_set_state(orc_env *h, const double *pos, const double *vel,
+                   const double *yaw, const double *pitch, const double *real_len,
+                   const double *max_dev, const double *extra_len,
+                   const int32_t *wp_idx, const uint8_t *arrive_f,
+                   const uint8_t *dest) {
+  size_t G = (size_t)h->E * h->N;
+  if (pos) memcpy(h->p, pos, G * 3 * sizeof(double));
+  if (vel) memcpy(h->v, vel, G * 3 * sizeof(double));
+  if (yaw) memcpy(h->yaw, yaw, G * sizeof(double));
+  if (pitch) memcpy(h->pitch, pitch, G * sizeof(double));
+  if (real_len) memcpy(h->real_len, real_len, G * sizeof(double));
+  if (max_dev) memcpy(h->max_dev, max_dev, G * sizeof(double));
+  if (extra_len) memcpy(h->extra_len, extra_len, G * sizeof(double));
+  if (wp_idx) memcpy(h->wp_idx, wp_idx, G * sizeof(int32_t));
+  if (arrive_f) memcpy(h->arrive, arrive_f, G);
+  if (dest) memcpy(h->dest, dest, G);
+}
+
+void orc_des_vel(const orc_env *h, double *des_vel) {
+  for (int g = 0; g < h->E * h->N; ++g)
+    cal_des_vel(h->p + 3 * (size_t)g, wp_at(h, g, h->wp_idx[g]), des_vel + 3 * (size_t)g);
+}
+
+void orc_vo_inf(orc_env *h, int e, int i, const double *action, double *rows,
+                int32_t *count, int32_t *vo_flag, double *tmin, int32_t *collision) {
+  work *w = work_alloc(h);
+  for (int k = 0; k < h->N; ++k) dronestate(h, e * h->N + k, &w->st[k]);
+  int c, f, col;
+  config_vo_inf(h, w->st, i, action, w->scratch, w->rows, &c, &f, tmin, &col);
+  memcpy(rows, w->rows, sizeof(double) * 9 * c);
+  *count = c; *vo_flag = f; *collision = col;
+  work_free(w);
+}
+
+int64_t orc_nan_count(const orc_env *h) { return h->nan_count; }
+void orc_set_threads(orc_env *h, int n) { h->threads = n < 1 ? 1 : n; }
