@@ -1,0 +1,376 @@
+// rvo3d_capi.hip -- the C-ABI of include/rvo3d.h over the gfx950 kernels.
+// Host side: handle + device buffers + launches.  No torch types, no
+// exceptions across the boundary, no allocation in step/observe.
+#include "../../include/rvo3d.h"
+#include "rvo3d_device.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using rvo3d::Params;
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                            \
+  do {                                                                           \
+    hipError_t _e = (expr);                                                      \
+    if (_e != hipSuccess)                                                        \
+      return fail(RVO3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+// x ** 2 as the reference computes it: glibc pow (the volatile exponent keeps
+// the compiler from folding the call into x * x).
+volatile double kTwo = 2.0;
+inline double py_sq(double x) { return std::pow(x, kTwo); }
+}  // namespace
+
+struct rvo3d_env {
+  rvo3d_config cfg;
+  Params P;             // pointers into `arena`
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  bool world_loaded = false;
+  int threads = 0, blocks = 0, lds = 0;
+};
+
+namespace {
+
+// One device allocation, carved into 256-B aligned struct-of-arrays fields.
+int carve(rvo3d_env* h) {
+  const rvo3d_config& c = h->cfg;
+  const size_t EN = (size_t)c.num_envs * c.num_drones;
+  struct Field { void** slot; size_t bytes; };
+  Params& P = h->P;
+  std::vector<Field> f = {
+      {(void**)&P.wp, (size_t)c.max_points * 3 * EN * 8},
+      {(void**)&P.n_points, EN * 4},
+      {(void**)&P.route_len, EN * 8},
+      {(void**)&P.radius, EN * 8},
+      {(void**)&P.prio, EN * 8},
+      {(void**)&P.bld, (size_t)(c.num_buildings > 0 ? c.num_buildings : 1) * 4 * 8},
+      {(void**)&P.pow95, (size_t)c.max_points * 8},
+      {(void**)&P.px, EN * 8}, {(void**)&P.py, EN * 8}, {(void**)&P.pz, EN * 8},
+      {(void**)&P.vx, EN * 8}, {(void**)&P.vy, EN * 8}, {(void**)&P.vz, EN * 8},
+      {(void**)&P.yaw, EN * 8}, {(void**)&P.pitch, EN * 8}, {(void**)&P.real_len, EN * 8},
+      {(void**)&P.max_dev, EN * 8}, {(void**)&P.extra_len, EN * 8},
+      {(void**)&P.wp_idx, EN * 4}, {(void**)&P.arrive, EN}, {(void**)&P.dest, EN},
+      {(void**)&P.err, 256},
+  };
+  size_t total = 0;
+  for (auto& x : f) total += align_up(x.bytes, 256);
+  HIP_TRY(hipMalloc(&h->arena, total));
+  HIP_TRY(hipMemset(h->arena, 0, total));
+  h->arena_bytes = total;
+  size_t off = 0;
+  for (auto& x : f) {
+    *x.slot = static_cast<char*>(h->arena) + off;
+    off += align_up(x.bytes, 256);
+  }
+  return RVO3D_OK;
+}
+
+int check(rvo3d_env* h, bool need_world) {
+  if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
+  if (need_world && !h->world_loaded)
+    return fail(RVO3D_ERR_STATE, "rvo3d_load_world has not been called");
+  hipError_t e = hipSetDevice(h->cfg.device);
+  if (e != hipSuccess) return fail(RVO3D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  return RVO3D_OK;
+}
+
+template <int MODE>
+int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
+  hipLaunchKernelGGL(rvo3d::env_kernel<MODE>, dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rvo3d_version(void) { return RVO3D_VERSION; }
+const char* rvo3d_last_error(void) { return g_err.c_str(); }
+
+int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
+  if (!cfg || !out) return fail(RVO3D_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->num_envs < 1 || cfg->num_drones < 1 || cfg->num_drones > rvo3d::kMaxThreads)
+    return fail(RVO3D_ERR_INVALID, "need num_envs >= 1 and 1 <= num_drones <= 512");
+  if (cfg->max_points < 2 || cfg->num_buildings < 0 || cfg->neighbors_num < 0)
+    return fail(RVO3D_ERR_INVALID, "need max_points >= 2, num_buildings >= 0, neighbors_num >= 0");
+  if ((long long)cfg->num_envs * cfg->num_drones > (1ll << 30))
+    return fail(RVO3D_ERR_INVALID, "num_envs * num_drones too large");
+  if (cfg->action_decimals > 9) return fail(RVO3D_ERR_INVALID, "action_decimals must be <= 9");
+  HIP_TRY(hipSetDevice(cfg->device));
+
+  rvo3d_env* h = new (std::nothrow) rvo3d_env();
+  if (!h) return fail(RVO3D_ERR_INVALID, "out of host memory");
+  h->cfg = *cfg;
+  Params& P = h->P;
+  std::memset(&P, 0, sizeof P);
+  P.E = cfg->num_envs; P.N = cfg->num_drones; P.P = cfg->max_points;
+  P.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
+  P.W = 12 + 9 * P.nm;
+  P.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
+  for (int k = 0; k < 3; ++k) P.map[k] = cfg->map_size[k];
+
+  // Launch geometry: whole envs per workgroup, about 256 threads, waves of 64.
+  const int N = P.N;
+  int epb = N >= 256 ? 1 : 256 / N;
+  if (epb > P.E) epb = P.E;
+  int threads = (int)align_up((size_t)epb * N, 64);
+  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb);
+  while (lds > 64 * 1024 && epb > 1) {  // keep >= 2 workgroups per CU where possible
+    epb = (epb + 1) / 2;
+    threads = (int)align_up((size_t)epb * N, 64);
+    lds = rvo3d::lds_bytes(threads, P.nm, epb);
+  }
+  if (lds > 160 * 1024) {
+    delete h;
+    return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");
+  }
+  P.epb = epb;
+  h->threads = threads;
+  h->blocks = (P.E + epb - 1) / epb;
+  h->lds = (int)lds;
+  if (lds > 64 * 1024) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+      delete h;
+      return fail(RVO3D_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    }
+  }
+  int rc = carve(h);
+  if (rc != RVO3D_OK) {
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return RVO3D_OK;
+}
+
+int rvo3d_destroy(rvo3d_env* h) {
+  if (!h) return RVO3D_OK;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  if (h->arena) (void)hipFree(h->arena);
+  delete h;
+  return RVO3D_OK;
+}
+
+int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_points,
+                     const double* buildings, const double* radius, const double* priority,
+                     void* stream) {
+  int rc = check(h, false);
+  if (rc) return rc;
+  if (!waypoints || !n_points) return fail(RVO3D_ERR_INVALID, "waypoints / n_points are required");
+  const Params& P = h->P;
+  if (P.nb > 0 && !buildings) return fail(RVO3D_ERR_INVALID, "buildings required when num_buildings > 0");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t EN = (size_t)P.E * P.N;
+  std::vector<double> wp((size_t)P.P * 3 * EN), rl(EN), rad(EN), pri(EN), p95(P.P);
+  for (size_t g = 0; g < EN; ++g) {
+    const int np = n_points[g];
+    if (np < 2 || np > P.P) return fail(RVO3D_ERR_INVALID, "n_points entries must be in [2, max_points]");
+    const double* src = waypoints + g * P.P * 3;
+    double total = 0.0;  // drone.calculate_total_length (drone.py:409-429)
+    for (int k = 0; k < P.P; ++k) {
+      const int kk = k < np ? k : np - 1;  // pad with the destination
+      for (int c = 0; c < 3; ++c) wp[((size_t)k * 3 + c) * EN + g] = src[kk * 3 + c];
+      if (k + 1 < np) {
+        const double dx = src[(k + 1) * 3] - src[k * 3], dy = src[(k + 1) * 3 + 1] - src[k * 3 + 1],
+                     dz = src[(k + 1) * 3 + 2] - src[k * 3 + 2];
+        total += std::sqrt(py_sq(dx) + py_sq(dy) + py_sq(dz));
+      }
+    }
+    rl[g] = total;
+    rad[g] = radius ? radius[g] : 0.2;
+    pri[g] = priority ? priority[g] : 5.0;
+  }
+  for (int k = 0; k < P.P; ++k) p95[k] = std::pow(0.95, (double)k);  // ir_gym.py:283
+  HIP_TRY(hipMemcpyAsync((void*)P.wp, wp.data(), wp.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.n_points, n_points, EN * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.route_len, rl.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.radius, rad.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.prio, pri.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.pow95, p95.data(), (size_t)P.P * 8, hipMemcpyHostToDevice, s));
+  if (P.nb > 0)
+    HIP_TRY(hipMemcpyAsync((void*)P.bld, buildings, (size_t)P.nb * 32, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(P.extra_len, 0, EN * 8, s));
+  const int tb = 256;
+  hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P,
+                     (const uint8_t*)nullptr, (const uint8_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));  // the host staging vectors die here
+  h->world_loaded = true;
+  return RVO3D_OK;
+}
+
+int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  const size_t EN = (size_t)h->P.E * h->P.N;
+  hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h->P, env_mask, (const uint8_t*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+
+int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  if (!drone_mask) return fail(RVO3D_ERR_INVALID, "drone_mask is required");
+  const size_t EN = (size_t)h->P.E * h->P.N;
+  hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h->P, (const uint8_t*)nullptr, drone_mask);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+
+int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  if (!obs || !vo_count) return fail(RVO3D_ERR_INVALID, "obs / vo_count are required");
+  Params P = h->P;
+  P.obs = obs; P.vo_count = vo_count;
+  return launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
+}
+
+static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
+                       int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
+                       uint8_t* finish, uint8_t* reset_mask, bool autoreset, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  if (!actions || !obs || !vo_count || !reward || !done || !info || !finish)
+    return fail(RVO3D_ERR_INVALID, "null I/O pointer");
+  if (action_dtype != RVO3D_F32 && action_dtype != RVO3D_F64)
+    return fail(RVO3D_ERR_INVALID, "action_dtype must be RVO3D_F32 or RVO3D_F64");
+  Params P = h->P;
+  P.actions = actions; P.action_f64 = action_dtype == RVO3D_F64;
+  P.obs = obs; P.vo_count = vo_count; P.reward = reward;
+  P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
+}
+
+int rvo3d_step(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
+               int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info, uint8_t* finish,
+               void* stream) {
+  return step_common(h, actions, action_dtype, obs, vo_count, reward, done, info, finish, nullptr,
+                     false, stream);
+}
+
+int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
+                         int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
+                         uint8_t* finish, uint8_t* reset_mask, void* stream) {
+  return step_common(h, actions, action_dtype, obs, vo_count, reward, done, info, finish,
+                     reset_mask, true, stream);
+}
+
+int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  if (!des_vel) return fail(RVO3D_ERR_INVALID, "des_vel is required");
+  const size_t EN = (size_t)h->P.E * h->P.N;
+  hipLaunchKernelGGL(rvo3d::des_vel_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h->P, des_vel);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+
+int rvo3d_state_ptrs(rvo3d_env* h, rvo3d_state_view* out) {
+  if (!h || !out) return fail(RVO3D_ERR_INVALID, "null argument");
+  const Params& P = h->P;
+  out->px = P.px; out->py = P.py; out->pz = P.pz; out->vx = P.vx; out->vy = P.vy; out->vz = P.vz;
+  out->yaw = P.yaw; out->pitch = P.pitch; out->real_len = P.real_len; out->max_dev = P.max_dev;
+  out->extra_len = P.extra_len; out->wp_idx = P.wp_idx; out->arrive = P.arrive; out->dest = P.dest;
+  return RVO3D_OK;
+}
+
+int rvo3d_get_state(rvo3d_env* h, double* pos, double* vel, double* yaw, double* pitch,
+                    double* real_len, double* max_dev, double* extra_len, int32_t* wp_idx,
+                    uint8_t* arrive, uint8_t* dest, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  const Params& P = h->P;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int EN = P.E * P.N;
+  const dim3 grid((EN + 255) / 256), blk(256);
+  if (pos) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.px, P.py, P.pz, pos, EN);
+  if (vel) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.vx, P.vy, P.vz, vel, EN);
+  HIP_TRY(hipGetLastError());
+  const hipMemcpyKind k = hipMemcpyDeviceToDevice;
+  if (yaw) HIP_TRY(hipMemcpyAsync(yaw, P.yaw, (size_t)EN * 8, k, s));
+  if (pitch) HIP_TRY(hipMemcpyAsync(pitch, P.pitch, (size_t)EN * 8, k, s));
+  if (real_len) HIP_TRY(hipMemcpyAsync(real_len, P.real_len, (size_t)EN * 8, k, s));
+  if (max_dev) HIP_TRY(hipMemcpyAsync(max_dev, P.max_dev, (size_t)EN * 8, k, s));
+  if (extra_len) HIP_TRY(hipMemcpyAsync(extra_len, P.extra_len, (size_t)EN * 8, k, s));
+  if (wp_idx) HIP_TRY(hipMemcpyAsync(wp_idx, P.wp_idx, (size_t)EN * 4, k, s));
+  if (arrive) HIP_TRY(hipMemcpyAsync(arrive, P.arrive, (size_t)EN, k, s));
+  if (dest) HIP_TRY(hipMemcpyAsync(dest, P.dest, (size_t)EN, k, s));
+  return RVO3D_OK;
+}
+
+int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const double* yaw,
+                    const double* pitch, const double* real_len, const double* max_dev,
+                    const double* extra_len, const int32_t* wp_idx, const uint8_t* arrive,
+                    const uint8_t* dest, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  const Params& P = h->P;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int EN = P.E * P.N;
+  const dim3 grid((EN + 255) / 256), blk(256);
+  if (pos) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, pos, P.px, P.py, P.pz, EN);
+  if (vel) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, vel, P.vx, P.vy, P.vz, EN);
+  HIP_TRY(hipGetLastError());
+  const hipMemcpyKind k = hipMemcpyDeviceToDevice;
+  if (yaw) HIP_TRY(hipMemcpyAsync(P.yaw, yaw, (size_t)EN * 8, k, s));
+  if (pitch) HIP_TRY(hipMemcpyAsync(P.pitch, pitch, (size_t)EN * 8, k, s));
+  if (real_len) HIP_TRY(hipMemcpyAsync(P.real_len, real_len, (size_t)EN * 8, k, s));
+  if (max_dev) HIP_TRY(hipMemcpyAsync(P.max_dev, max_dev, (size_t)EN * 8, k, s));
+  if (extra_len) HIP_TRY(hipMemcpyAsync(P.extra_len, extra_len, (size_t)EN * 8, k, s));
+  if (wp_idx) HIP_TRY(hipMemcpyAsync(P.wp_idx, wp_idx, (size_t)EN * 4, k, s));
+  if (arrive) HIP_TRY(hipMemcpyAsync(P.arrive, arrive, (size_t)EN, k, s));
+  if (dest) HIP_TRY(hipMemcpyAsync(P.dest, dest, (size_t)EN, k, s));
+  return RVO3D_OK;
+}
+
+int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
+  int rc = check(h, false);
+  if (rc) return rc;
+  if (!flags) return fail(RVO3D_ERR_INVALID, "flags is required");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipMemcpyAsync(flags, h->P.err, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemsetAsync(h->P.err, 0, 4, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return RVO3D_OK;
+}
+
+int rvo3d_launch_info(rvo3d_env* h, int32_t* threads, int32_t* envs_per_block, int32_t* blocks,
+                      int32_t* lds_bytes) {
+  if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
+  if (threads) *threads = h->threads;
+  if (envs_per_block) *envs_per_block = h->P.epb;
+  if (blocks) *blocks = h->blocks;
+  if (lds_bytes) *lds_bytes = h->lds;
+  return RVO3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,654 @@
+// rvo3d_device.hpp -- gfx950 device code of the batched 3D-RVO drone step.
+//
+// One thread = one drone; a workgroup holds EPB whole environments so the
+// whole step (RVO reward sweep -> integrate -> observation sweep -> optional
+// auto-reset + re-observe) is ONE launch with workgroup barriers between the
+// phases.  Neighbour position / velocity / radius / priority are staged in LDS
+// (64 B per drone); the O(N^2) sweep is two-stage: a full-utilisation gate
+// loop builds a 64-bit in-range mask per lane, then only set bits run the
+// cone / time-to-collision code.
+//
+// Decision arithmetic is fp64 and follows the reference's evaluation order
+// (compile with -ffp-contract=off; the explicit __builtin_fma calls model the
+// OpenBLAS ddot the reference goes through, see DESIGN.md "arithmetic model").
+// Reference citations are relative to the reference root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvo3d {
+
+constexpr double kGoalThreshold = 0.4;   // drone.py:15
+constexpr double kNeighborGate = 10.0;   // rvo_inter.py:96
+constexpr double kBuildingGate = 5.0;    // rvo_inter.py:104
+constexpr double kCtimeThreshold = 2.0;  // rvo_inter.py:11
+constexpr double kExpRadius = 0.2;       // rvo_inter.py:11
+constexpr double kDeg2Rad = 0.017453292519943295;
+constexpr double kPi = 3.141592653589793;
+constexpr int kMaxThreads = 512;
+
+struct Params {
+  int E, N, P, nb, nm, env_train, epb, W;
+  int action_f64;     // 1: actions are double
+  double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
+  double map[3];
+  // static world (SoA over EN = E*N)
+  const double* wp;        // [P][3][EN]
+  const int32_t* n_points; // [EN]
+  const double* route_len; // [EN]
+  const double* radius;    // [EN]
+  const double* prio;      // [EN]
+  const double* bld;       // [nb][4]
+  const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
+  // mutable state
+  double *px, *py, *pz, *vx, *vy, *vz, *yaw, *pitch, *real_len, *max_dev, *extra_len;
+  int32_t* wp_idx;
+  uint8_t *arrive, *dest;
+  uint32_t* err;
+  // per-call I/O
+  const void* actions;
+  float* obs;
+  int32_t* vo_count;
+  float* reward;
+  uint8_t *done, *info, *finish, *reset_mask;
+};
+
+// ---- arithmetic primitives -------------------------------------------------
+__device__ __forceinline__ double sq(double x) { return x * x; }  // reference: pow(x, 2)
+__device__ __forceinline__ double dot3b(double ax, double ay, double az, double bx,
+                                        double by, double bz) {
+  return __builtin_fma(az, bz, __builtin_fma(ay, by, ax * bx));  // OpenBLAS ddot, n = 3
+}
+__device__ __forceinline__ double norm3b(double x, double y, double z) {
+  return __builtin_sqrt(dot3b(x, y, z, x, y, z));
+}
+__device__ __forceinline__ double norm2b(double x, double y) {
+  return __builtin_sqrt(__builtin_fma(y, y, x * x));
+}
+__device__ __forceinline__ double np_round2(double x) { return __builtin_rint(x * 100.0) / 100.0; }
+__device__ __forceinline__ double np_round3(double x) { return __builtin_rint(x * 1000.0) / 1000.0; }
+
+// Python round(x, 2): correctly rounded decimal, ties to even (vel_obs3D.py:15).
+// Returns the integer c with round(x, 2) == c / 100.0.
+__device__ __forceinline__ double py_round2_c(double x) {
+  double p = x * 100.0;
+  double e = __builtin_fma(x, 100.0, -p);
+  double c = __builtin_floor(p);
+  double d = (p - (c + 0.5)) + e;
+  if (d > 0.0) c += 1.0;
+  else if (d == 0.0 && (((long long)c) & 1)) c += 1.0;
+  return c;
+}
+__device__ __forceinline__ double clampd(double x, double lo, double hi) {
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+__device__ __forceinline__ double np_mod(double a, double b) {  // npy_divmod remainder
+  double m = fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0.0) != (m < 0.0)) m += b;
+  } else {
+    m = __builtin_copysign(0.0, b);
+  }
+  return m;
+}
+
+// ---- per-drone pieces --------------------------------------------------------
+// drone.cal_des_vel (drone.py:199-210, 340-352, 319-328)
+__device__ __forceinline__ void des_vel(const double p[3], const double cur[3], double out[3]) {
+  double dx = cur[0] - p[0], dy = cur[1] - p[1], dz = cur[2] - p[2];
+  double dis = norm3b(dx, dy, dz);
+  if (dis > kGoalThreshold) {
+    double az = atan2(dy, dx);
+    double el = atan2(dz, norm2b(dx, dy));
+    double sa, ca, se, ce;
+    sincos(az, &sa, &ca);
+    sincos(el, &se, &ce);
+    out[0] = np_round3(1.0 * (ca * ce));
+    out[1] = np_round3(1.0 * (sa * ce));
+    out[2] = np_round3(1.0 * se);
+  } else {
+    out[0] = out[1] = out[2] = 0.0;
+  }
+}
+
+// drone.calculate_deviation (drone.py:366-406)
+__device__ __forceinline__ double deviation(const double a[3], const double b[3],
+                                            const double p[3]) {
+  double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+  double mag = __builtin_sqrt(sq(dx) + sq(dy) + sq(dz));
+  if (mag == 0.0) return 0.0;
+  double hx = dx / mag, hy = dy / mag, hz = dz / mag;
+  double qx0 = p[0] - a[0], qy0 = p[1] - a[1], qz0 = p[2] - a[2];
+  double t = qx0 * hx + qy0 * hy + qz0 * hz;
+  double qx = a[0] + t * hx, qy = a[1] + t * hy, qz = a[2] + t * hz;
+  return __builtin_sqrt(sq(p[0] - qx) + sq(p[1] - qy) + sq(p[2] - qz));
+}
+
+__device__ __forceinline__ bool arrived(const double p[3], const double d[3]) {
+  return norm3b(p[0] - d[0], p[1] - d[1], p[2] - d[2]) <= kGoalThreshold;  // drone.py:172
+}
+
+// vel_obs3D.cal_vo_exp_tim (vel_obs3D.py:145-182)
+__device__ __forceinline__ double vo_exp_time(double rx, double ry, double rz, double rvx,
+                                              double rvy, double rvz, double ra, double rb) {
+  double r = ra + rb;
+  double ux = -rvx, uy = -rvy, uz = -rvz;
+  double a = sq(ux) + sq(uy) + sq(uz);
+  double b = 2 * rx * ux + 2 * ry * uy + 2 * rz * uz;
+  double c = sq(rx) + sq(ry) + sq(rz) - sq(r);
+  if (c <= 0) return 0.0;
+  double temp = sq(b) - 4 * a * c;
+  if (temp <= 0) return __builtin_inf();
+  double s = __builtin_sqrt(temp);
+  double t1 = (-b + s) / (2 * a);
+  double t2 = (-b - s) / (2 * a);
+  if (t1 < 0 && t2 < 0) return -1.0;
+  double t3 = t1 >= 0 ? t1 : __builtin_inf();
+  double t4 = t2 >= 0 ? t2 : __builtin_inf();
+  return t4 < t3 ? t4 : t3;  // python min(t3, t4)
+}
+
+struct Drone {  // the 8 values a neighbour contributes (drone.dronestate[0:8])
+  double x, y, z, vx, vy, vz, r, prio;
+};
+
+struct PairOut {
+  bool collision, flag;
+  double t, iet, md;
+  double alpha_c;  // alpha == alpha_c / 100.0
+};
+
+// rvo_inter.config_vo_circle2 (rvo_inter.py:116-196) + get_alpha / get_PAA /
+// vo_out_jud_vector / get_beta (vel_obs3D.py:8-66, rvo_inter.py:212-228).
+// `a` is the action after the "< 1e-5 -> 0" rule (rvo_inter.py:118).
+__device__ __forceinline__ PairOut pair_eval(const Drone& S, const Drone& O, const double a[3],
+                                             int env_train) {
+  PairOut o;
+  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0.0;
+  double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
+  double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
+  double R = S.r + O.r;
+  if (env_train) {
+    if (dis <= R) o.collision = true;
+  } else {
+    if (dis <= S.r - kExpRadius + O.r) o.collision = true;
+  }
+  if (o.collision) return o;
+  double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
+  if (dotp <= 0) return o;
+  double nab = norm3b(rx, ry, rz);
+  o.alpha_c = py_round2_c(asin(R / nab));
+  double pr = S.prio / (S.prio + O.prio);
+  double paax = pr * (2 * S.x + (S.vx + O.vx));
+  double paay = pr * (2 * S.y + (S.vy + O.vy));
+  double paaz = pr * (2 * S.z + (S.vz + O.vz));
+  double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay, wz = (S.z + 2 * a[2]) - paaz;
+  double dp = dot3b(rx, ry, rz, wx, wy, wz);
+  double AB = nab * norm3b(wx, wy, wz);
+  double cosang = (AB != 0) ? dp / AB : 0.0;
+  double beta = np_round2(acos(cosang));  // NaN when |cos| > 1 (np.arccos)
+  double t = __builtin_inf();
+  if (o.alpha_c / 100.0 > beta) {
+    double rvx = 2 * a[0] - O.vx - S.vx, rvy = 2 * a[1] - O.vy - S.vy,
+           rvz = 2 * a[2] - O.vz - S.vz;
+    t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, O.r);
+    if (t < kCtimeThreshold) o.flag = true;
+    else t = __builtin_inf();
+  }
+  o.t = t;
+  o.iet = 1 / (t + 0.2);
+  o.md = dis - O.r;
+  return o;
+}
+
+// ---- LDS views ---------------------------------------------------------------
+struct Lds {
+  double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T]
+  double* iet;                                   // [nm][T] kept VO rows, ascending urgency
+  uint32_t* pk;                                  // [nm][T] (alpha_c << 16) | j
+  int* any_reset;                                // [epb]
+  int T;
+};
+
+__device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb) {
+  Lds L;
+  double* d = reinterpret_cast<double*>(base);
+  L.x = d; L.y = d + T; L.z = d + 2 * T; L.vx = d + 3 * T; L.vy = d + 4 * T; L.vz = d + 5 * T;
+  L.r = d + 6 * T; L.prio = d + 7 * T;
+  L.iet = d + 8 * T;
+  L.pk = reinterpret_cast<uint32_t*>(L.iet + (size_t)nm * T);
+  L.any_reset = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
+  L.T = T;
+  return L;
+}
+__host__ __device__ inline size_t lds_bytes(int T, int nm, int epb) {
+  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)epb * 4 + 16;
+}
+
+__device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
+  Drone d;
+  d.x = L.x[k]; d.y = L.y[k]; d.z = L.z[k]; d.vx = L.vx[k]; d.vy = L.vy[k]; d.vz = L.vz[k];
+  d.r = L.r[k]; d.prio = L.prio[k];
+  return d;
+}
+
+// min_dis of a kept row, recomputed from LDS exactly as pair_eval computed it.
+__device__ __forceinline__ double pair_md(const Drone& S, const Drone& O) {
+  double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
+  return __builtin_sqrt(sq(ry) + sq(rx) + sq(rz)) - O.r;
+}
+
+// Sweep over the other drones of my env (rvo_inter.preprocess gate,
+// rvo_inter.py:85-97, then config_vo_circle2 per in-range neighbour).
+//   ROWS = false: config_vo_reward (rvo_inter.py:63-83)  -> flag, tmin
+//   ROWS = true : config_vo_inf   (rvo_inter.py:20-61)   -> + collision, kept rows in LDS
+// Kept rows: the nm most urgent in the order of list.sort(reverse=True,
+// key=(-iet, min_dis)) (stable): ascending iet, then descending min_dis, then
+// ascending j; slot 0 = least urgent kept.  Returns the number kept.
+template <bool ROWS>
+__device__ __forceinline__ int sweep(const Params& P, const Lds& L, int tid, int lbase,
+                                     const Drone& S, const double a[3], bool& flag,
+                                     double& tmin, bool& collision) {
+  flag = false;
+  tmin = __builtin_inf();
+  int kept = 0;
+  const int N = P.N, T = L.T;
+  for (int c0 = 0; c0 < N; c0 += 64) {
+    const int cn = (N - c0) < 64 ? (N - c0) : 64;
+    unsigned long long mask = 0ull;
+    for (int jj = 0; jj < cn; ++jj) {  // gate: full lane utilisation
+      const int k = lbase + c0 + jj;
+      const double ox = L.x[k], oy = L.y[k], oz = L.z[k];
+      const bool same = (S.x == ox) && (S.y == oy) && (S.z == oz);  // rvo_inter.py:92
+      const double dist = norm3b(S.x - ox, S.y - oy, S.z - oz);
+      if (!same && dist <= kNeighborGate) mask |= (1ull << jj);
+    }
+    while (mask) {  // only in-range neighbours
+      const int jj = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int j = c0 + jj;
+      const Drone O = lds_drone(L, lbase + j);
+      const PairOut po = pair_eval(S, O, a, P.env_train);
+      if (ROWS && po.collision) collision = true;
+      if (po.flag) {
+        flag = true;
+        if (po.t < tmin) tmin = po.t;
+        if (ROWS && P.nm > 0) {
+          // position among kept rows: first slot whose row is more urgent than the new one
+          int pos = kept;
+          for (int s = 0; s < kept; ++s) {
+            const double ie = L.iet[s * T + tid];
+            bool new_first;  // new row sorts before slot s
+            if (po.iet != ie) new_first = po.iet < ie;
+            else {
+              const int js = (int)(L.pk[s * T + tid] & 0xffffu);
+              const double mds = pair_md(S, lds_drone(L, lbase + js));
+              new_first = (po.md != mds) ? (po.md > mds) : (j < js);
+            }
+            if (new_first) { pos = s; break; }
+          }
+          const uint32_t packed = ((uint32_t)po.alpha_c << 16) | (uint32_t)j;
+          if (kept < P.nm) {  // grow: shift [pos, kept) up by one
+            for (int s = kept; s > pos; --s) {
+              L.iet[s * T + tid] = L.iet[(s - 1) * T + tid];
+              L.pk[s * T + tid] = L.pk[(s - 1) * T + tid];
+            }
+            L.iet[pos * T + tid] = po.iet;
+            L.pk[pos * T + tid] = packed;
+            ++kept;
+          } else if (pos > 0) {  // full: drop slot 0 (least urgent), insert at pos-1
+            for (int s = 0; s < pos - 1; ++s) {
+              L.iet[s * T + tid] = L.iet[(s + 1) * T + tid];
+              L.pk[s * T + tid] = L.pk[(s + 1) * T + tid];
+            }
+            L.iet[(pos - 1) * T + tid] = po.iet;
+            L.pk[(pos - 1) * T + tid] = packed;
+          }
+        }
+      }
+    }
+  }
+  return kept;
+}
+
+// building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
+__device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
+  bool hit = false;
+  for (int b = 0; b < P.nb; ++b) {
+    const double bx = P.bld[4 * b], by = P.bld[4 * b + 1], bh = P.bld[4 * b + 2],
+                 br = P.bld[4 * b + 3];
+    if (bh > S.z - 2) {
+      if (norm2b(S.x - bx, S.y - by) <= kBuildingGate) {
+        if (S.z <= bh) {
+          double dis = __builtin_sqrt(sq(S.x - bx) + sq(S.y - by));
+          if (dis <= S.r + br) hit = true;
+        }
+      }
+    }
+  }
+  return hit;
+}
+
+// Writes one observation row: np.round(concat[12 proprio, kept VO rows], 2)
+// (ir_gym.py:208-229 / :353-355), zero padded to 12 + 9*nm floats.
+__device__ __forceinline__ void write_obs(const Params& P, const Lds& L, int tid, int lbase,
+                                          int g, const Drone& S, const double dv[3],
+                                          double dev, int kept) {
+  float* o = P.obs + (size_t)g * P.W;
+  bool bad = false;
+  double v[12] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio, dv[0], dv[1], dv[2], dev};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    double q = np_round2(v[k]);
+    bad |= !(__builtin_fabs(q) < __builtin_inf());
+    o[k] = (float)q;
+  }
+  for (int s = 0; s < kept; ++s) {
+    const uint32_t pk = L.pk[s * L.T + tid];
+    const int j = (int)(pk & 0xffffu);
+    const Drone O = lds_drone(L, lbase + j);
+    const double pr = S.prio / (S.prio + O.prio);
+    double row[9];
+    row[0] = pr * (2 * S.x + (S.vx + O.vx));  // get_PAA, vel_obs3D.py:19-32
+    row[1] = pr * (2 * S.y + (S.vy + O.vy));
+    row[2] = pr * (2 * S.z + (S.vz + O.vz));
+    row[3] = O.x - S.x; row[4] = O.y - S.y; row[5] = O.z - S.z;
+    row[6] = (double)(pk >> 16) / 100.0;
+    row[7] = pair_md(S, O);
+    row[8] = L.iet[s * L.T + tid];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      double q = np_round2(row[k]);
+      bad |= !(__builtin_fabs(q) < __builtin_inf());
+      o[12 + 9 * s + k] = (float)q;
+    }
+  }
+  for (int k = 12 + 9 * kept; k < P.W; ++k) o[k] = 0.0f;
+  P.vo_count[g] = kept;
+  if (bad) atomicOr(P.err, 1u);
+}
+
+__device__ __forceinline__ void load_wp(const Params& P, int g, int k, double out[3]) {
+  const size_t EN = (size_t)P.E * P.N;
+  out[0] = P.wp[((size_t)k * 3 + 0) * EN + g];
+  out[1] = P.wp[((size_t)k * 3 + 1) * EN + g];
+  out[2] = P.wp[((size_t)k * 3 + 2) * EN + g];
+}
+
+// ir_gym.rvo_reward_cal (ir_gym.py:64-133) after config_vo_reward
+__device__ __forceinline__ double rvo_reward(const double dv[3], const double a[3], bool flag,
+                                             double tmin) {
+  const double d0 = np_round3(dv[0]), d1 = np_round3(dv[1]), d2 = np_round3(dv[2]);
+  const double vel_penalty = 0.2 * norm3b(a[0], a[1], a[2]) / norm3b(d0, d1, d2);
+  const double eps = 1e-8;
+  const double magA = __builtin_sqrt(sq(d0) + sq(d1) + sq(d2) + eps);
+  const double magB = __builtin_sqrt(sq(a[0]) + sq(a[1]) + sq(a[2]) + eps);
+  const double dotp = d0 * a[0] + d1 * a[1] + d2 * a[2];
+  double ang;
+  if (magA < 1e-6 || magB < 1e-6) ang = 0.0;
+  else {
+    double c = dotp / (magA * magB);
+    c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c);
+    ang = acos(c);
+  }
+  double punish;
+  if (-kPi / 18 < ang && ang < kPi / 18) punish = 3;
+  else if (-kPi / 6 < ang && ang < kPi / 6) punish = 1;
+  else if (-kPi / 3 < ang && ang < kPi / 3) punish = 0.5;
+  else if (-kPi / 2 < ang && ang < kPi / 2) punish = 0;
+  else punish = -4;
+  double safety = 0;
+  if (flag) {
+    double urgency = 0;
+    if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
+    safety = -2.5 + urgency;
+  }
+  return np_round3(punish + vel_penalty + safety);
+}
+
+// ir_gym.mov_reward (ir_gym.py:256-311)
+__device__ __forceinline__ double mov_reward(const Params& P, bool collision, bool arrive_r,
+                                             int waypoint_num, int n_points_m1, bool dest_r,
+                                             double dev, bool len_flag, double exlen) {
+  if (collision) return -50.0;
+  double reward = 0;
+  if (arrive_r) reward += 3.0 * P.pow95[n_points_m1 - waypoint_num];
+  if (dest_r) reward += 20.0;
+  const double d = dev * 10;
+  const double dev_pen = -1.5 * (2 / (1 + exp(-(d - 5) / 0.3)));
+  double ex_pen = 0;
+  if (len_flag) {
+    ex_pen = -0.3 * log(exlen + 1 + 1e-6);
+    if (ex_pen < -6 || ex_pen != ex_pen) ex_pen = -6;
+  }
+  return np_round3(reward + dev_pen + ex_pen);
+}
+
+enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
+
+// The whole environment step, one launch.
+template <int MODE>
+__global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, T = blockDim.x, N = P.N;
+  const Lds L = carve_lds(smem, T, P.nm, P.epb);
+  const int el = tid / N;
+  const int d = tid - el * N;
+  const int e = blockIdx.x * P.epb + el;
+  const bool active = (el < P.epb) && (e < P.E);
+  const int g = active ? e * N + d : 0;
+  const int lbase = el * N;
+
+  double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
+  double yaw = 0, pitch = 0, real_len = 0, max_dev = 0, extra_len = 0, route_len = 0;
+  double cur[3] = {0, 0, 0}, prev[3] = {0, 0, 0}, dst[3] = {0, 0, 0}, dv[3], dev = 0;
+  int wpi = 1, npts = 2;
+  bool f_arrive = false, f_dest = false;
+  Drone S;
+  S.r = 0.2; S.prio = 5;
+
+  if (active) {
+    p[0] = P.px[g]; p[1] = P.py[g]; p[2] = P.pz[g];
+    v[0] = P.vx[g]; v[1] = P.vy[g]; v[2] = P.vz[g];
+    max_dev = P.max_dev[g];
+    wpi = P.wp_idx[g];
+    S.r = P.radius[g]; S.prio = P.prio[g];
+    load_wp(P, g, wpi, cur);
+    load_wp(P, g, wpi - 1, prev);
+    if (MODE != kObserve) {
+      yaw = P.yaw[g]; pitch = P.pitch[g]; real_len = P.real_len[g];
+      extra_len = P.extra_len[g]; route_len = P.route_len[g];
+      npts = P.n_points[g];
+      f_arrive = P.arrive[g] != 0; f_dest = P.dest[g] != 0;
+      load_wp(P, g, npts - 1, dst);
+      if (P.action_f64) {
+        const double* A = static_cast<const double*>(P.actions) + (size_t)g * 3;
+        a[0] = A[0]; a[1] = A[1]; a[2] = A[2];
+      } else {
+        const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
+        a[0] = (double)A[0]; a[1] = (double)A[1]; a[2] = (double)A[2];
+      }
+      if (P.act_scale > 0) {
+        a[0] = __builtin_rint(a[0] * P.act_scale) / P.act_scale;
+        a[1] = __builtin_rint(a[1] * P.act_scale) / P.act_scale;
+        a[2] = __builtin_rint(a[2] * P.act_scale) / P.act_scale;
+      }
+    }
+    // drone.dronestate on the pre-move state (drone.py:254-263)
+    des_vel(p, cur, dv);
+    dev = deviation(prev, cur, p);
+    if (dev > max_dev) max_dev = dev;
+  }
+  if (tid < P.epb) L.any_reset[tid] = 0;
+  L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
+  L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
+  L.r[tid] = S.r; L.prio[tid] = S.prio;
+  __syncthreads();
+  S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
+
+  bool flag, collision = false;
+  double tmin;
+  const double zero3[3] = {0, 0, 0};
+
+  if (MODE == kObserve) {
+    if (active) {
+      const int kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, collision);
+      write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
+      P.max_dev[g] = max_dev;
+    }
+    return;
+  }
+
+  // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
+  double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
+  if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
+  double rew = 0;
+  if (active) {
+    sweep<false>(P, L, tid, lbase, S, az, flag, tmin, collision);
+    rew = rvo_reward(dv, a, flag, tmin);
+  }
+  __syncthreads();  // everyone is done with the pre-move LDS image
+
+  // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490)
+  if (active) {
+    double speed = norm3b(v[0], v[1], v[2]);
+    const double acc = clampd(a[0] * 1.0, -1.0, 1.0);
+    const double dyaw = clampd(a[1] * 90.0, -90.0, 90.0);
+    const double dpit = clampd(a[2] * 90.0, -90.0, 90.0);
+    const double nv = speed + acc;
+    speed = (0.0 > nv) ? 0.0 : nv;
+    yaw = np_mod(yaw + dyaw, 360.0);
+    pitch = clampd(pitch + dpit, -90.0, 90.0);
+    double sy, cy, sp, cp;
+    sincos(yaw * kDeg2Rad, &sy, &cy);
+    sincos(pitch * kDeg2Rad, &sp, &cp);
+    double nvx = speed * cp * cy, nvy = speed * cp * sy, nvz = speed * sp;
+    if (f_dest) nvx = nvy = nvz = 0.0;  // `stop` := map_size (env_base.py:142, drone.py:107)
+    const double q0 = p[0], q1 = p[1], q2 = p[2];
+    p[0] = p[0] + nvx; p[1] = p[1] + nvy; p[2] = p[2] + nvz;
+    v[0] = nvx; v[1] = nvy; v[2] = nvz;
+    real_len = real_len + norm3b(p[0] - q0, p[1] - q1, p[2] - q2);
+    if (arrived(p, cur)) {  // drone.py:116-129
+      bool at_dst = arrived(p, dst);
+      if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
+      if (!at_dst && wpi < npts - 1) {
+        wpi += 1;
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        load_wp(P, g, wpi, cur);
+        f_arrive = false;
+      }
+    }
+    // dronestate on the post-move state
+    des_vel(p, cur, dv);
+    dev = deviation(prev, cur, p);
+    if (dev > max_dev) max_dev = dev;
+  }
+  L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
+  L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
+  __syncthreads();
+  S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
+
+  // ---- sweep B: ir_gym.observation_reward on the post-move state (ir_gym.py:156-254)
+  bool do_reset = false;
+  if (active) {
+    bool arrive_r = false, dest_r = false;
+    const int waypoint_num = wpi;
+    if (arrived(p, cur) && !f_arrive) { f_arrive = true; arrive_r = true; }
+    if (f_arrive) {
+      if (arrived(p, dst)) {
+        extra_len = real_len - route_len;
+        if (!f_dest) { f_dest = true; dest_r = true; }
+      }
+    }
+    const double exlen = real_len - route_len + 4;
+    const bool len_flag = exlen > 0;
+    collision = building_hit(P, S);
+    const int kept = sweep<true>(P, L, tid, lbase, S, az, flag, tmin, collision);
+    if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
+        p[2] > P.map[2])
+      collision = true;  // drone.drone_out_map, drone.py:213-225
+    write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
+    const double mr = mov_reward(P, collision, arrive_r, waypoint_num, npts - 1, dest_r, dev,
+                                 len_flag, exlen);
+    P.reward[g] = (float)(rew + mr);  // mdin.py:28
+    P.done[g] = collision ? 1 : 0;
+    P.info[g] = f_arrive ? 1 : 0;
+    P.finish[g] = f_dest ? 1 : 0;
+    do_reset = (MODE == kStepAutoReset) && (collision || f_dest);
+  }
+
+  if (MODE == kStepAutoReset) {
+    if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
+    if (do_reset) L.any_reset[el] = 1;
+    __syncthreads();  // sweep B reads done; any_reset visible
+    const bool env_reset = active && (L.any_reset[el] != 0);
+    if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
+      load_wp(P, g, 0, p);
+      v[0] = v[1] = v[2] = 0.0;
+      wpi = 1; f_arrive = false; f_dest = false;
+      real_len = 0.0; max_dev = 0.0; yaw = 0.0; pitch = 0.0;
+      load_wp(P, g, 1, cur);
+      prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2];
+      des_vel(p, cur, dv);
+      dev = deviation(prev, cur, p);
+      if (dev > max_dev) max_dev = dev;
+      L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
+      L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
+    }
+    __syncthreads();
+    if (env_reset) {  // ir_gym.env_observation for the whole env (ir_gym.py:372-383)
+      S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
+      bool c2 = false;
+      const int kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, c2);
+      write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
+    }
+  }
+
+  if (active) {
+    P.px[g] = p[0]; P.py[g] = p[1]; P.pz[g] = p[2];
+    P.vx[g] = v[0]; P.vy[g] = v[1]; P.vz[g] = v[2];
+    P.yaw[g] = yaw; P.pitch[g] = pitch; P.real_len[g] = real_len;
+    P.max_dev[g] = max_dev; P.extra_len[g] = extra_len;
+    P.wp_idx[g] = wpi;
+    P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
+  }
+}
+
+// ---- small state kernels -------------------------------------------------------
+// drone.reset (drone.py:270-291) for masked envs / drones.
+__global__ void reset_kernel(const Params P, const uint8_t* env_mask, const uint8_t* drone_mask) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.E * P.N) return;
+  if (env_mask && !env_mask[g / P.N]) return;
+  if (drone_mask && !drone_mask[g]) return;
+  double s[3];
+  load_wp(P, g, 0, s);
+  P.px[g] = s[0]; P.py[g] = s[1]; P.pz[g] = s[2];
+  P.vx[g] = 0.0; P.vy[g] = 0.0; P.vz[g] = 0.0;
+  P.wp_idx[g] = 1; P.arrive[g] = 0; P.dest[g] = 0;
+  P.real_len[g] = 0.0; P.max_dev[g] = 0.0; P.yaw[g] = 0.0; P.pitch[g] = 0.0;
+}
+
+__global__ void des_vel_kernel(const Params P, double* out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.E * P.N) return;
+  double p[3] = {P.px[g], P.py[g], P.pz[g]}, cur[3], dv[3];
+  load_wp(P, g, P.wp_idx[g], cur);
+  des_vel(p, cur, dv);
+  out[3 * (size_t)g] = dv[0]; out[3 * (size_t)g + 1] = dv[1]; out[3 * (size_t)g + 2] = dv[2];
+}
+
+// AoS <-> SoA copies for get_state / set_state
+__global__ void aos3_to_soa(const double* src, double* x, double* y, double* z, int n) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  x[g] = src[3 * (size_t)g]; y[g] = src[3 * (size_t)g + 1]; z[g] = src[3 * (size_t)g + 2];
+}
+__global__ void soa_to_aos3(const double* x, const double* y, const double* z, double* dst, int n) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  dst[3 * (size_t)g] = x[g]; dst[3 * (size_t)g + 1] = y[g]; dst[3 * (size_t)g + 2] = z[g];
+}
+
+}  // namespace rvo3d

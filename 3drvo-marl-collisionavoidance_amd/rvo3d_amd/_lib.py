@@ -1,0 +1,109 @@
+"""Loader for librvo3d_hip.so (the C-ABI of include/rvo3d.h) via ctypes.
+
+The library is built in-tree (next to this file) by `build_hip()`:
+    hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared ...
+No fallback exists: a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_SO = os.path.join(_HERE, "librvo3d_hip.so")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+               "-std=c++17"]
+
+
+class RVO3DError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def sources():
+    return [os.path.join(_CSRC, "rvo3d_capi.hip"), os.path.join(_CSRC, "rvo3d_device.hpp"),
+            os.path.join(_ROOT, "include", "rvo3d.h")]
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP extension for gfx950 (cross-compiles without a GPU)."""
+    src = sources()
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(f) > os.path.getmtime(_SO) for f in src)
+    if force or stale:
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", _SO, src[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return _SO
+
+
+class Config(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_drones", C.c_int32), ("max_points", C.c_int32),
+                ("num_buildings", C.c_int32), ("neighbors_num", C.c_int32),
+                ("env_train", C.c_int32), ("device", C.c_int32), ("action_decimals", C.c_int32),
+                ("map_size", C.c_double * 3)]
+
+
+class StateView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("px", "py", "pz", "vx", "vy", "vz", "yaw", "pitch", "real_len", "max_dev",
+                 "extra_len", "wp_idx", "arrive", "dest")]
+
+
+# every symbol include/rvo3d.h declares (tests check the library exports them all)
+SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
+           "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
+           "rvo3d_des_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
+           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_version", "rvo3d_last_error")
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library (ctypes.CDLL) with argtypes set."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = C.CDLL(_SO)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.rvo3d_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.rvo3d_destroy.argtypes = [vp]
+    L.rvo3d_load_world.argtypes = [vp] * 7
+    L.rvo3d_reset.argtypes = [vp, vp, vp]
+    L.rvo3d_reset_drones.argtypes = [vp, vp, vp]
+    L.rvo3d_observe.argtypes = [vp, vp, vp, vp]
+    L.rvo3d_step.argtypes = [vp, vp, i32] + [vp] * 7
+    L.rvo3d_step_autoreset.argtypes = [vp, vp, i32] + [vp] * 8
+    L.rvo3d_des_vel.argtypes = [vp, vp, vp]
+    L.rvo3d_state_ptrs.argtypes = [vp, C.POINTER(StateView)]
+    L.rvo3d_get_state.argtypes = [vp] * 12
+    L.rvo3d_set_state.argtypes = [vp] * 12
+    L.rvo3d_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.rvo3d_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.rvo3d_version.restype = i32
+    L.rvo3d_last_error.restype = C.c_char_p
+    for s in SYMBOLS:
+        if s not in ("rvo3d_version", "rvo3d_last_error"):
+            getattr(L, s).restype = i32
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().rvo3d_last_error().decode("utf-8", "replace")
+        raise RVO3DError(f"{what} failed ({rc}): {msg}")

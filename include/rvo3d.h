@@ -1,0 +1,159 @@
+/*
+ * rvo3d.h -- C-ABI of the MI355X-native batched 3D-RVO drone environment
+ * (librvo3d_hip.so; HIP kernels for gfx950 behind plain-C entry points).
+ *
+ * The reference (ZSHCRWY25/3DRVO-MARL-CollisionAvoidance) is pure Python and
+ * has no FFI of its own; the boundary this library drops in under is the
+ * Python surface of `uaisa_env.drone_envs.mdin.mdin`.  Each entry point names
+ * the reference method it replaces (paths relative to the reference root).
+ * The Python binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - E environments x N drones; drone (e, d) has flat index e*N + d.
+ *   - Unless marked HOST, every pointer is a DEVICE pointer owned by the
+ *     caller (e.g. torch tensors) and only borrowed for the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued on it; nothing synchronises unless stated.
+ *   - Every function returns RVO3D_OK or a negative error; the message for
+ *     the calling thread's last error is rvo3d_last_error().  Nothing throws.
+ *   - A handle is bound to one device, is not re-entrant, and owns its state
+ *     buffers; step/observe allocate nothing.
+ */
+#ifndef RVO3D_H
+#define RVO3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVO3D_VERSION 1
+
+enum {
+  RVO3D_OK = 0,
+  RVO3D_ERR_INVALID = -1,  /* bad argument / unsupported configuration */
+  RVO3D_ERR_HIP = -2,      /* a HIP runtime call failed                */
+  RVO3D_ERR_STATE = -3     /* call order (e.g. step before load_world) */
+};
+
+enum { RVO3D_F32 = 0, RVO3D_F64 = 1 };
+
+/* bits of the device error word (rvo3d_error_flags) */
+enum {
+  RVO3D_FLAG_NONFINITE_OBS = 1 /* an observation held NaN/Inf: the reference
+                                  raises ValueError here (ir_gym.py:232-239) */
+};
+
+typedef struct rvo3d_env rvo3d_env;
+
+typedef struct rvo3d_config {
+  int32_t num_envs;       /* E >= 1                                            */
+  int32_t num_drones;     /* N, 1..512   (data_1.json "drone_num")             */
+  int32_t max_points;     /* P >= 2: longest route, in waypoints               */
+  int32_t num_buildings;  /* nb >= 0, shared by all envs ("building_list")     */
+  int32_t neighbors_num;  /* nm: VO rows kept per observation (mdin.py:7, 10)  */
+  int32_t env_train;      /* rvo_inter.py:14 (1 = reference default)           */
+  int32_t device;         /* HIP device ordinal                                */
+  int32_t action_decimals;/* >= 0: actions are re-quantised on device to that
+                             many decimals in fp64 (rint(a*10^d)/10^d), so a
+                             float32 buffer of 2-decimal values is widened to
+                             exactly the fp64 the reference steps with
+                             (multi_ppo.py:205); -1: widen as is               */
+  double map_size[3];     /* data_1.json "map_size"                            */
+} rvo3d_config;
+
+/* Device views of the handle's struct-of-arrays state, each [E*N]. Valid
+ * until rvo3d_destroy. (reach-through used by the trainer: drone_list[i].vel,
+ * multi_ppo.py:202; indicators_*, ir_gym.py:414-420) */
+typedef struct rvo3d_state_view {
+  double *px, *py, *pz;       /* drone.state                                   */
+  double *vx, *vy, *vz;       /* drone.vel                                     */
+  double *yaw, *pitch;        /* degrees (drone.py:68-69)                      */
+  double *real_len;           /* drone.real_route_len                          */
+  double *max_dev;            /* drone.max_deviation                           */
+  double *extra_len;          /* drone.extra_len                               */
+  int32_t *wp_idx;            /* drone.i                                       */
+  uint8_t *arrive, *dest;     /* arrive_flag, destination_arrive_flag          */
+} rvo3d_state_view;
+
+/* mdin.__init__ -> ir_gym.__init__ -> env_base.__init__ (mdin.py:7,
+ * ir_gym.py:18, env_base.py:15): allocate state for E x N drones. */
+int rvo3d_create(const rvo3d_config *cfg, rvo3d_env **out);
+int rvo3d_destroy(rvo3d_env *h);
+
+/* env_base.load_data + env_drone.__init__ (env_base.py:26-47,
+ * env_drones.py:13-32).  HOST pointers: waypoints [E][N][P][3] (routes shorter
+ * than P padded with anything), n_points [E][N] (each 2..P), buildings
+ * [nb][4] = x,y,h,r, radius / priority [E][N] or NULL for 0.2 / 5
+ * (drone.py:14-15).  Copies to the device, computes route lengths
+ * (drone.py:409-429) and puts every drone in its reset state.  Synchronises. */
+int rvo3d_load_world(rvo3d_env *h, const double *waypoints, const int32_t *n_points,
+                     const double *buildings, const double *radius,
+                     const double *priority, void *stream);
+
+/* env_drone.drones_reset (env_drones.py:99) for the envs whose mask byte is
+ * non-zero (env_mask NULL = every env). env_mask [E]. */
+int rvo3d_reset(rvo3d_env *h, const uint8_t *env_mask, void *stream);
+/* mdin.drone_reset_one (mdin.py:43) for every drone whose mask byte is
+ * non-zero. drone_mask [E][N]. */
+int rvo3d_reset_drones(rvo3d_env *h, const uint8_t *drone_mask, void *stream);
+
+/* ir_gym.env_observation / the observation half of ir_gym.env_reset
+ * (ir_gym.py:360-383): observations of every drone with action = 0.
+ * obs [E][N][12+9*nm] float32, rows beyond vo_count zero; vo_count [E][N]
+ * (0 = the reference's single all-zero VO row). */
+int rvo3d_observe(rvo3d_env *h, float *obs, int32_t *vo_count, void *stream);
+
+/* mdin.drone_step (mdin.py:19-30): RVO reward sweep on the pre-move state,
+ * kinematic integration, observation / reward / termination sweep on the
+ * post-move state.  actions [E][N][3] of action_dtype (RVO3D_F32 / RVO3D_F64).
+ * reward [E][N] float32 = rvo_reward + mov_reward (may be inf/nan exactly where
+ * the reference's is, ir_gym.py:88); done = collision, info = arrive_flag,
+ * finish = destination_arrive_flag (ir_gym.py:248-250), all [E][N] bytes. */
+int rvo3d_step(rvo3d_env *h, const void *actions, int32_t action_dtype, float *obs,
+               int32_t *vo_count, float *reward, uint8_t *done, uint8_t *info,
+               uint8_t *finish, void *stream);
+
+/* rvo3d_step fused with the caller protocol of multi_ppo.py:230-242/266-281:
+ * drones with done|finish are reset and every env that reset a drone has all
+ * its observations recomputed with action = 0 (ir_gym.env_observation).
+ * reset_mask [E][N] (nullable) reports the drones that were reset; reward /
+ * done / info / finish are those of the step itself. */
+int rvo3d_step_autoreset(rvo3d_env *h, const void *actions, int32_t action_dtype,
+                         float *obs, int32_t *vo_count, float *reward, uint8_t *done,
+                         uint8_t *info, uint8_t *finish, uint8_t *reset_mask,
+                         void *stream);
+
+/* ir_gym.cal_des_list (ir_gym.py:44): desired velocity, des_vel [E][N][3] f64. */
+int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
+
+/* Zero-copy views of the state arrays. */
+int rvo3d_state_ptrs(rvo3d_env *h, rvo3d_state_view *out);
+/* Array-of-structs copies: pos/vel [E][N][3] f64, the rest [E][N]; any
+ * pointer may be NULL.  set_state is for tests and checkpoint restore. */
+int rvo3d_get_state(rvo3d_env *h, double *pos, double *vel, double *yaw, double *pitch,
+                    double *real_len, double *max_dev, double *extra_len,
+                    int32_t *wp_idx, uint8_t *arrive, uint8_t *dest, void *stream);
+int rvo3d_set_state(rvo3d_env *h, const double *pos, const double *vel,
+                    const double *yaw, const double *pitch, const double *real_len,
+                    const double *max_dev, const double *extra_len,
+                    const int32_t *wp_idx, const uint8_t *arrive, const uint8_t *dest,
+                    void *stream);
+
+/* Reads (and clears) the device error word into *flags (HOST).  Synchronises
+ * the stream: opt-in, keep it out of the rollout loop. */
+int rvo3d_error_flags(rvo3d_env *h, uint32_t *flags, void *stream);
+
+/* Launch geometry chosen for this handle (diagnostics / bench):
+ * threads per block, envs per block, blocks, dynamic LDS bytes. */
+int rvo3d_launch_info(rvo3d_env *h, int32_t *threads, int32_t *envs_per_block,
+                      int32_t *blocks, int32_t *lds_bytes);
+
+int rvo3d_version(void);
+const char *rvo3d_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

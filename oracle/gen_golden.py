@@ -307,7 +307,7 @@ def _variant_lib():
     src = os.path.join(ROOT, "oracle", "rvo3d_oracle.c")
     if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
         subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-DORC_VARIANT=1",
-                               "-ffp-contract=off", "-fopenmp", "-o", so, src, "-lm"])
+                               "-ffp-contract=off", "-fno-builtin-pow", "-fopenmp", "-o", so, src, "-lm"])
     return so
 
 
@@ -368,6 +368,31 @@ def _replay(fx, orc):
             if not (_eq(oa[0], fx["obs_after"][t]) and np.array_equal(ca[0], fx["vo_count_after"][t])):
                 bad.append(f"t={t} obs_after")
     return bad
+
+
+def oracle_margins(fx):
+    """Per (step, drone) minimum decision margin (oracle/rvo3d_oracle.h
+    orc_get_margin), covering the step and the re-observation after resets."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    env = orc.OracleEnv(fx["waypoints"][None], fx["n_points"][None], fx["map_size"],
+                        fx["buildings"], nm=int(fx["nm"]), env_train=bool(fx["env_train"]),
+                        radius=np.full(fx["n_points"][None].shape, float(fx["radius"])))
+    env.observe()
+    m0 = env.margin()[0]
+    out = []
+    for t in range(fx["actions"].shape[0]):
+        if "set_pos" in fx:
+            env.set_state(pos=fx["set_pos"][t][None], vel=fx["set_vel"][t][None],
+                          yaw=fx["set_yaw"][t][None], pitch=fx["set_pitch"][t][None])
+        env.step(fx["actions"][t][None])
+        m = env.margin()[0]
+        if fx["reset_mask"][t].any():
+            env.reset_drones(fx["reset_mask"][t][None])
+            env.observe()
+            m = np.minimum(m, env.margin()[0])
+        out.append(m)
+    return m0, np.stack(out)
 
 
 # --------------------------------------------------------------------------
@@ -502,6 +527,7 @@ def main():
         if fx is None:
             print(f"DROPPED {name}")
             continue
+        fx["margin0"], fx["margin"] = oracle_margins(fx)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **fx)
         kept += 1
         ev = dict(steps=int(fx["actions"].shape[0] * fx["actions"].shape[1]),
@@ -511,7 +537,8 @@ def main():
                                       fx["finish"].astype(np.int8)]), axis=0).clip(0).sum()),
                   wp_switch=int((np.diff(fx["state_wp_idx"], axis=0) > 0).sum()),
                   resets=int(fx["reset_mask"].sum()),
-                  nonfinite_reward=int((~np.isfinite(fx["reward"])).sum()))
+                  nonfinite_reward=int((~np.isfinite(fx["reward"])).sum()),
+                  knife_edge=int((fx["margin"] < 1e-9).sum()))
         summary[name] = ev
         print(f"kept {name}: {ev}")
     with open(os.path.join(OUT, "SUMMARY.json"), "w") as f:

@@ -50,6 +50,7 @@ def lib():
         L.orc_set_state.argtypes = [vp] + [dp] * 7 + [ip, bp, bp]
         L.orc_des_vel.argtypes = [vp, dp]
         L.orc_vo_inf.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, ip, dp, ip]
+        L.orc_get_margin.argtypes = [vp, dp, ip]
         L.orc_nan_count.restype = C.c_int64
         L.orc_nan_count.argtypes = [vp]
         L.orc_set_threads.argtypes = [vp, C.c_int]
@@ -183,6 +184,18 @@ class OracleEnv:
         lib().orc_vo_inf(self._h, int(e), int(i), _dp(a), _dp(rows), _ip(cnt), _ip(flag),
                          _dp(tmin), _ip(col))
         return rows[:cnt[0]].copy(), bool(flag[0]), float(tmin[0]), bool(col[0])
+
+    def margin(self):
+        """Per-drone minimum decision margin of the last observe/step call."""
+        out = np.empty((self.E, self.N))
+        lib().orc_get_margin(self._h, _dp(out), None)
+        return out
+
+    def margin_sites(self):
+        """(margin, source line in rvo3d_oracle.c of the decision that set it)."""
+        out, site = np.empty((self.E, self.N)), np.zeros((self.E, self.N), np.int32)
+        lib().orc_get_margin(self._h, _dp(out), _ip(site))
+        return out, site
 
     @property
     def nan_count(self):

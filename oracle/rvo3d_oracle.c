@@ -52,6 +52,9 @@ struct orc_env {
   int32_t *wp_idx;
   uint8_t *arrive, *dest;
   int64_t nan_count;
+  double *margin;     /* [E*N] min decision margin of the last call (audit) */
+  int32_t *msite;     /* [E*N] source line of the decision that set it */
+  uint8_t *vnoise;    /* [E*N] velocity came out of a cancelled speed (pure libm noise) */
 };
 
 /* ---- arithmetic primitives ------------------------------------------- */
@@ -71,6 +74,31 @@ static inline double dot3_blas(const double *a, const double *b) {
 static inline double norm2_blas(double x, double y) { return sqrt(x * x + y * y); }
 #endif
 static inline double norm3_blas(const double *a) { return sqrt(dot3_blas(a, a)); }
+
+/* ---- decision-margin audit ------------------------------------------------
+ * Every branch / rounding whose outcome could flip under a 1-ulp change of a
+ * libm result reports |value - threshold| here; the minimum per drone and call
+ * is kept in h->margin.  Tests allow a device/oracle mismatch only on samples
+ * whose margin is below 1e-9 (the reference's own result is libm noise there). */
+static _Thread_local double *tl_margin = 0;
+static _Thread_local int32_t *tl_site = 0;
+static inline void mgs0(int site, double d) {
+  d = fabs(d);
+  if (tl_margin && d < *tl_margin) { *tl_margin = d; *tl_site = site; }
+}
+/* value == threshold EXACTLY is reproducible (exact input data: integer
+ * coordinates, 3-4-5 distances, acos(0)); only a near tie is a knife edge.
+ * The one exception is the speed cancellation in move_forward (mg0 there). */
+static inline void mgs(int site, double d) { if (d != 0) mgs0(site, d); }
+static inline void mgs_round(int site, double x, double f) { /* distance of x to a rounding tie */
+  if (!isfinite(x)) return;
+  double p = x * f;
+  mgs(site, (fabs(p - floor(p) - 0.5)) / f);
+}
+#define mg(d) mgs(__LINE__, (d))
+#define mg0(d) mgs0(__LINE__, (d))
+#define mgx(d) mgs(__LINE__, (d))
+#define mg_round(x, f) mgs_round(__LINE__, (x), (f))
 
 double orc_np_round(double x, int decimals) {
   /* numpy round: multiply, rint, true_divide */
@@ -109,9 +137,10 @@ static void cal_des_vel(const double *p, const double *cur_des, double *out) {
   double dis = norm3_blas(dif);
   double az = atan2(dif[1], dif[0]);
   double el = (dis != 0.0) ? atan2(dif[2], norm2_blas(dif[0], dif[1])) : 0.0;
+  mg(dis - GOAL_THRESHOLD);
   if (dis > GOAL_THRESHOLD) {
     double dir[3] = {cos(az) * cos(el), sin(az) * cos(el), sin(el)};
-    for (int k = 0; k < 3; ++k) out[k] = np_round3(1.0 * dir[k]);
+    for (int k = 0; k < 3; ++k) { mg_round(dir[k], 1000.0); out[k] = np_round3(1.0 * dir[k]); }
   } else {
     out[0] = out[1] = out[2] = 0.0;
   }
@@ -138,6 +167,7 @@ static inline void cur_prev_des(const orc_env *h, int g, const double **cur,
 
 /* drone.dronestate (drone.py:254-263), incl. the max_deviation side effect */
 static void dronestate(orc_env *h, int g, dstate *o) {
+  tl_margin = h->margin + g; tl_site = h->msite + g;
   const double *cur, *prev;
   cur_prev_des(h, g, &cur, &prev);
   const double *p = h->p + 3 * (size_t)g, *v = h->v + 3 * (size_t)g;
@@ -153,7 +183,9 @@ static void dronestate(orc_env *h, int g, dstate *o) {
 
 static inline int arrive(const double *p, const double *des) {
   double d[3] = {p[0] - des[0], p[1] - des[1], p[2] - des[2]};
-  return norm3_blas(d) <= GOAL_THRESHOLD; /* drone.py:172-179 */
+  double dist = norm3_blas(d);
+  mg(dist - GOAL_THRESHOLD);
+  return dist <= GOAL_THRESHOLD; /* drone.py:172-179 */
 }
 /* drone.destination_arrive (drone.py:182-192): side effect on extra_len */
 static inline int destination_arrive(orc_env *h, int g) {
@@ -183,12 +215,21 @@ static inline double clampd(double x, double lo, double hi) {
  * drone.py:96-129), with kinematicstep (drone.py:435-490).  `stop` receives
  * map_size (truthy) because of the argument shift at env_base.py:142. */
 static void move_forward(orc_env *h, int g, const double *act) {
+  tl_margin = h->margin + g; tl_site = h->msite + g;
   double *p = h->p + 3 * (size_t)g, *v = h->v + 3 * (size_t)g;
   double speed = norm3_blas(v);                           /* drone.py:103 */
   double acc = clampd(act[0] * MAX_ACC, -MAX_ACC, MAX_ACC);
   double dyaw = clampd(act[1] * MAX_ANGLE, -MAX_ANGLE, MAX_ANGLE);
   double dpit = clampd(act[2] * MAX_ANGLE, -MAX_ANGLE, MAX_ANGLE);
   double nv = speed + acc * 1;
+  /* speed clamp at 0: when ||v|| (libm noise in its last bit) cancels against
+   * the decimal acc, the sign of nv - and with it whether the new velocity is
+   * 0 or 1e-17 * direction - is noise.  v == 0 exactly gives nv = acc: robust. */
+  h->vnoise[g] = 0;
+  if (v[0] != 0 || v[1] != 0 || v[2] != 0) {
+    mg0(nv);
+    if (fabs(nv) < 1e-9) h->vnoise[g] = 1;
+  }
   speed = (0.0 > nv) ? 0.0 : nv;                          /* python max(nv, 0), drone.py:452 */
   h->yaw[g] = np_mod(h->yaw[g] + dyaw, 360.0);
   h->pitch[g] = clampd(h->pitch[g] + dpit, -90.0, 90.0);
@@ -227,11 +268,14 @@ static double cal_vo_exp_tim(double rx, double ry, double rz, double rvx,
   double a = sq(ux) + sq(uy) + sq(uz);
   double b = 2 * rx * ux + 2 * ry * uy + 2 * rz * uz;
   double c = sq(rx) + sq(ry) + sq(rz) - sq(r);
+  mg(c);
   if (c <= 0) return 0.0;
   double temp = sq(b) - 4 * a * c;
+  mg(temp);
   if (temp <= 0) return INFINITY;
   double t1 = (-b + sqrt(temp)) / (2 * a);
   double t2 = (-b - sqrt(temp)) / (2 * a);
+  mg(t1); mg(t2);
   if (t1 < 0 && t2 < 0) return -1.0;
   double t3 = t1 >= 0 ? t1 : INFINITY;
   double t4 = t2 >= 0 ? t2 : INFINITY;
@@ -252,6 +296,7 @@ static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O
   double dis = sqrt(sq(rel[1]) + sq(rel[0]) + sq(rel[2]));
   double real_dis = dis;
   int collision = 0;
+  mg(dis - (r + mr));
   if (h->env_train) {
     if (dis <= r + mr) { dis = r + mr; collision = 1; }
   } else {
@@ -264,11 +309,14 @@ static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O
   out->min_dis = dis;
   if (collision) return;                                   /* rvo_inter.py:152 */
   double dotp = vx * rel[0] + vy * rel[1] + vz * rel[2];
+  mg(dotp); /* v == 0 exactly (reset / clamped speed) gives dotp == 0: robust */
   if (dotp <= 0) return;                                   /* rvo_inter.py:159 */
 
   /* get_alpha */
   double ab[3] = {mx - x, my - y, mz - z};
-  double alpha = orc_py_round2(asin((r + mr) / norm3_blas(ab)));
+  double alpha_raw = asin((r + mr) / norm3_blas(ab));
+  mg_round(alpha_raw, 100.0);
+  double alpha = orc_py_round2(alpha_raw);
   /* get_PAA */
   double pr = S->s[7] / (S->s[7] + O->s[7]);
   double paa[3] = {pr * (2 * x + (vx + mvx) * 1), pr * (2 * y + (vy + mvy) * 1),
@@ -282,11 +330,15 @@ static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O
   double dp = dot3_blas(rel, w);
   double AB = norm3_blas(rel) * norm3_blas(w);
   double cosang = (AB != 0) ? dp / AB : 0.0;
-  double beta = np_round2(acos(cosang)); /* NaN when |cos| > 1, as np.arccos */
+  mg(fabs(cosang) - 1.0);
+  double beta_raw = acos(cosang); /* NaN when |cos| > 1, as np.arccos */
+  mg_round(beta_raw, 100.0);
+  double beta = np_round2(beta_raw);
   double t = INFINITY;
   int flag = 0;
   if (alpha > beta) { /* inside the cone */
     t = cal_vo_exp_tim(rel[0], rel[1], rel[2], rvx, rvy, rvz, r, mr);
+    mg(t - CTIME_THRESHOLD);
     if (t < CTIME_THRESHOLD) flag = 1;
     else t = INFINITY;
   }
@@ -304,7 +356,9 @@ static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O
 static inline int in_gate(const dstate *S, const dstate *O) {
   if (S->s[0] == O->s[0] && S->s[1] == O->s[1] && S->s[2] == O->s[2]) return 0;
   double dif[3] = {S->s[0] - O->s[0], S->s[1] - O->s[1], S->s[2] - O->s[2]};
-  return norm3_blas(dif) <= NEIGHBOR_GATE;
+  double dist = norm3_blas(dif);
+  mg(dist - NEIGHBOR_GATE);
+  return dist <= NEIGHBOR_GATE;
 }
 
 /* building gate (rvo_inter.py:99-105) + check_col_with_budilding (:198-209) */
@@ -312,10 +366,15 @@ static int building_collision(const orc_env *h, const dstate *S) {
   int hit = 0;
   for (int b = 0; b < h->nb; ++b) {
     const double *B = h->bld + 4 * b;
+    mgx(B[2] - (S->s[2] - 2));
     if (B[2] > S->s[2] - 2) {
-      if (norm2_blas(S->s[0] - B[0], S->s[1] - B[1]) <= BUILDING_GATE) {
+      double d2 = norm2_blas(S->s[0] - B[0], S->s[1] - B[1]);
+      mg(d2 - BUILDING_GATE);
+      if (d2 <= BUILDING_GATE) {
+        mgx(S->s[2] - B[2]);
         if (S->s[2] <= B[2]) {
           double dis = sqrt(sq(S->s[0] - B[0]) + sq(S->s[1] - B[1]));
+          mg(dis - (S->s[6] + B[3]));
           if (dis <= S->s[6] + B[3]) hit = 1;
         }
       }
@@ -346,7 +405,9 @@ typedef struct { double iet, md; int j; double obs[9]; } vo_row;
 
 static int row_before(const vo_row *a, const vo_row *b) {
   /* a precedes b in list.sort(reverse=True, key=(-iet, min_dis)) (stable) */
+  if (a->iet != b->iet) mg((a->iet - b->iet) / (fabs(a->iet) + 1e-300));
   if (-a->iet != -b->iet) return -a->iet > -b->iet;
+  if (a->md != b->md) mg(a->md - b->md);
   if (a->md != b->md) return a->md > b->md;
   return a->j < b->j;
 }
@@ -406,6 +467,7 @@ static double rvo_reward_cal(const orc_env *h, const dstate *all, int i,
     c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c); /* np.clip */
     ang = acos(c);
   }
+  mg(ang - M_PI / 18); mg(ang - M_PI / 6); mg(ang - M_PI / 3); mgx(ang - M_PI / 2);
   double angle_punish;
   if (-M_PI / 18 < ang && ang < M_PI / 18) angle_punish = 3;
   else if (-M_PI / 6 < ang && ang < M_PI / 6) angle_punish = 1;
@@ -418,6 +480,7 @@ static double rvo_reward_cal(const orc_env *h, const dstate *all, int i,
     if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
     safety = -2.5 + urgency;
   }
+  mg_round(angle_punish + vel_penalty + safety, 1000.0);
   return np_round3(angle_punish + vel_penalty + safety);
 }
 
@@ -434,12 +497,15 @@ static double mov_reward(int collision, int arrive_reward, int waypoint_num,
   double exlen_penalty = 0;
   if (len_flag) {
     exlen_penalty = -0.3 * log(exlen + 1 + 1e-6);
+    mg(exlen_penalty + 6);
     if (exlen_penalty < -6 || exlen_penalty != exlen_penalty) exlen_penalty = -6;
   }
+  mg_round(reward + dev_penalty + exlen_penalty, 1000.0);
   return np_round3(reward + dev_penalty + exlen_penalty);
 }
 
 static int out_of_map(const orc_env *h, const double *p) { /* drone.py:213-225 */
+  for (int k = 0; k < 3; ++k) { mgx(p[k]); mgx(p[k] - h->map[k]); }
   return p[0] < 0 || p[0] > h->map[0] || p[1] < 0 || p[1] > h->map[1] ||
          p[2] < 0 || p[2] > h->map[2];
 }
@@ -447,8 +513,13 @@ static int out_of_map(const orc_env *h, const double *p) { /* drone.py:213-225 *
 static void write_obs(orc_env *h, const dstate *S, const double *rows, int count,
                       double *obs) {
   int W = 12 + 9 * h->nm, bad = 0;
-  for (int k = 0; k < 12; ++k) obs[k] = np_round2(S->s[k]);
-  for (int k = 0; k < 9 * count; ++k) obs[12 + k] = np_round2(rows[k]);
+  for (int k = 0; k < 12; ++k) {
+    /* radius, priority and des_vel (already a 3-decimal value: its own rounding
+     * is audited in cal_des_vel) are decimals, not libm results: a tie is robust */
+    if (k < 6 || k == 11) mg_round(S->s[k], 100.0);
+    obs[k] = np_round2(S->s[k]);
+  }
+  for (int k = 0; k < 9 * count; ++k) { mg_round(rows[k], 100.0); obs[12 + k] = np_round2(rows[k]); }
   for (int k = 12 + 9 * count; k < W; ++k) obs[k] = 0.0;
   for (int k = 0; k < W; ++k) if (!isfinite(obs[k])) bad = 1;
   if (bad) {
@@ -469,6 +540,7 @@ static void env_observe(orc_env *h, int e, work *w, double *obs, int32_t *vo_cou
   for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
   for (int i = 0; i < N; ++i) {
     int cnt, vf, col; double tmin;
+    tl_margin = h->margin + (e * N + i); tl_site = h->msite + (e * N + i);
     config_vo_inf(h, w->st, i, zero, w->scratch, w->rows, &cnt, &vf, &tmin, &col);
     write_obs(h, &w->st[i], w->rows, cnt, obs + (size_t)(e * N + i) * W);
     vo_count[e * N + i] = cnt;
@@ -481,14 +553,18 @@ static void env_step(orc_env *h, int e, work *w, const double *actions, double *
   const int N = h->N, W = 12 + 9 * h->nm;
   /* sweep A: ir_gym.rvo_reward_list_cal (ir_gym.py:50-62) on pre-move states */
   for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
-  for (int i = 0; i < N; ++i)
+  for (int i = 0; i < N; ++i) {
+    tl_margin = h->margin + (e * N + i); tl_site = h->msite + (e * N + i);
+    if (h->vnoise[e * N + i]) mg0(0.0); /* pre-move velocity is the noise left by the last step */
     reward[e * N + i] = rvo_reward_cal(h, w->st, i, actions + 3 * (size_t)(e * N + i));
+  }
   /* integrate: env_base.drone_step (env_base.py:135-144) */
   for (int i = 0; i < N; ++i) move_forward(h, e * N + i, actions + 3 * (size_t)(e * N + i));
   /* sweep B: ir_gym.obs_move_reward_list / observation_reward (ir_gym.py:136-254) */
   for (int i = 0; i < N; ++i) dronestate(h, e * N + i, &w->st[i]);
   for (int i = 0; i < N; ++i) {
     const int g = e * N + i;
+    tl_margin = h->margin + g; tl_site = h->msite + g;
     const double *p = h->p + 3 * (size_t)g;
     int arrive_reward = 0, dest_reward = 0;
     int waypoint_num = h->wp_idx[g];
@@ -505,6 +581,7 @@ static void env_step(orc_env *h, int e, work *w, const double *actions, double *
     }
     double deviation = w->st[i].s[11];
     double exlen = h->real_len[g] - h->route_len[g] + 4;
+    mg(exlen);
     int len_flag = exlen > 0;
     int cnt, vf, col; double tmin;
     config_vo_inf(h, w->st, i, actions + 3 * (size_t)g, w->scratch, w->rows, &cnt,
@@ -531,6 +608,7 @@ static void reset_drone(orc_env *h, int g) { /* drone.reset, drone.py:270-291 */
   h->max_dev[g] = 0.0;
   h->yaw[g] = 0.0;
   h->pitch[g] = 0.0;
+  h->vnoise[g] = 0;
   /* extra_len is NOT cleared by the reference's reset */
 }
 
@@ -559,6 +637,9 @@ orc_env *orc_create(int E, int N, int P, int nb, int nm, int env_train,
   h->wp_idx = (int32_t *)calloc(G, sizeof(int32_t));
   h->arrive = (uint8_t *)calloc(G, 1);
   h->dest = (uint8_t *)calloc(G, 1);
+  h->margin = (double *)calloc(G, sizeof(double));
+  h->msite = (int32_t *)calloc(G, sizeof(int32_t));
+  h->vnoise = (uint8_t *)calloc(G, 1);
   return h;
 }
 
@@ -567,7 +648,7 @@ void orc_destroy(orc_env *h) {
   free(h->wp); free(h->n_points); free(h->route_len); free(h->radius); free(h->prio);
   free(h->bld); free(h->p); free(h->v); free(h->yaw); free(h->pitch);
   free(h->real_len); free(h->max_dev); free(h->extra_len); free(h->wp_idx);
-  free(h->arrive); free(h->dest); free(h);
+  free(h->arrive); free(h->dest); free(h->margin); free(h->msite); free(h->vnoise); free(h);
 }
 
 void orc_load_world(orc_env *h, const double *waypoints, const int32_t *n_points,
@@ -612,7 +693,17 @@ static work *work_alloc(const orc_env *h) {
 }
 static void work_free(work *w) { free(w->st); free(w->scratch); free(w->rows); free(w); }
 
+static void margin_clear(orc_env *h) {
+  for (int g = 0; g < h->E * h->N; ++g) h->margin[g] = INFINITY;
+}
+
+void orc_get_margin(const orc_env *h, double *out, int32_t *site) {
+  if (out) memcpy(out, h->margin, (size_t)h->E * h->N * sizeof(double));
+  if (site) memcpy(site, h->msite, (size_t)h->E * h->N * sizeof(int32_t));
+}
+
 void orc_observe(orc_env *h, double *obs, int32_t *vo_count) {
+  margin_clear(h);
 #ifdef _OPENMP
 #pragma omp parallel num_threads(h->threads)
 #endif
@@ -628,6 +719,7 @@ void orc_observe(orc_env *h, double *obs, int32_t *vo_count) {
 
 void orc_step(orc_env *h, const double *actions, double *obs, int32_t *vo_count,
               double *reward, uint8_t *done, uint8_t *info, uint8_t *finish) {
+  margin_clear(h);
 #ifdef _OPENMP
 #pragma omp parallel num_threads(h->threads)
 #endif
@@ -645,6 +737,7 @@ void orc_step(orc_env *h, const double *actions, double *obs, int32_t *vo_count,
 void orc_step_autoreset(orc_env *h, const double *actions, double *obs,
                         int32_t *vo_count, double *reward, uint8_t *done,
                         uint8_t *info, uint8_t *finish, uint8_t *reset_mask) {
+  margin_clear(h);
 #ifdef _OPENMP
 #pragma omp parallel num_threads(h->threads)
 #endif
@@ -711,7 +804,9 @@ void orc_des_vel(const orc_env *h, double *des_vel) {
 void orc_vo_inf(orc_env *h, int e, int i, const double *action, double *rows,
                 int32_t *count, int32_t *vo_flag, double *tmin, int32_t *collision) {
   work *w = work_alloc(h);
+  margin_clear(h);
   for (int k = 0; k < h->N; ++k) dronestate(h, e * h->N + k, &w->st[k]);
+  tl_margin = h->margin + (e * h->N + i); tl_site = h->msite + (e * h->N + i);
   int c, f, col;
   config_vo_inf(h, w->st, i, action, w->scratch, w->rows, &c, &f, tmin, &col);
   memcpy(rows, w->rows, sizeof(double) * 9 * c);

@@ -82,6 +82,13 @@ void orc_des_vel(const orc_env *h, double *des_vel);
 void orc_vo_inf(orc_env *h, int e, int i, const double *action, double *rows,
                 int32_t *count, int32_t *vo_flag, double *tmin, int32_t *collision);
 
+/* Decision-margin audit: for every drone, the smallest |value - threshold|
+ * over all branches and roundings evaluated for it by the LAST observe / step
+ * call (absolute units; +inf if none).  Where this is below ~1e-9 the
+ * reference's own outcome is decided by libm rounding noise, and a device
+ * result may legitimately differ.  out [E][N]. */
+void orc_get_margin(const orc_env *h, double *out, int32_t *site /* source line, may be NULL */);
+
 /* Number of observations that contained NaN/Inf since creation (the
  * reference raises ValueError, ir_gym.py:232-239). */
 int64_t orc_nan_count(const orc_env *h);

@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for
+gfx950, loads, and exports every symbol include/rvo3d.h declares.  No compute
+calls (those need a GPU and live in the `-m gpu` tests)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from rvo3d_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def so():
+    return _lib.build_hip()
+
+
+def test_header_symbols_all_exported(so):
+    hdr = open(os.path.join(ROOT, "include", "rvo3d.h")).read()
+    declared = set(re.findall(r"\b(rvo3d_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    L = C.CDLL(so)
+    for s in declared:
+        assert hasattr(L, s), f"{s} not exported"
+
+
+def test_version_and_error_string(so):
+    L = _lib.lib()
+    assert L.rvo3d_version() == 1
+    assert isinstance(L.rvo3d_last_error(), bytes)
+
+
+def test_bad_arguments_return_status_not_crash(so):
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.rvo3d_create(None, C.byref(h)) == -1          # RVO3D_ERR_INVALID
+    cfg = _lib.Config(0, 4, 2, 0, 10, 1, 0, -1, (C.c_double * 3)(10, 10, 5))
+    assert L.rvo3d_create(C.byref(cfg), C.byref(h)) == -1   # num_envs < 1
+    assert b"num_envs" in L.rvo3d_last_error()
+    cfg = _lib.Config(1, 4096, 2, 0, 10, 1, 0, -1, (C.c_double * 3)(10, 10, 5))
+    assert L.rvo3d_create(C.byref(cfg), C.byref(h)) == -1   # N > 512
+    assert L.rvo3d_step(None, None, 0, None, None, None, None, None, None, None) == -1
+    assert L.rvo3d_destroy(None) == 0
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through the CPU oracle."""
+    pkg = os.path.join(ROOT, "3drvo-marl-collisionavoidance_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in txt and "rvo3d_oracle" not in txt, f
+                assert "orc_" not in txt, f
