@@ -31,6 +31,15 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // the compiler from folding the call into x * x).
 volatile double kTwo = 2.0;
 inline double py_sq(double x) { return std::pow(x, kTwo); }
+
+// max{x : sqrt(x) <= tau} for the host's correctly rounded sqrt: `norm <= tau`
+// in the reference is exactly `norm^2 <= sq_threshold(tau)` on the device.
+double sq_threshold(double tau) {
+  volatile double x = tau * tau;
+  while (std::sqrt(std::nextafter((double)x, INFINITY)) <= tau) x = std::nextafter((double)x, INFINITY);
+  while (std::sqrt((double)x) > tau) x = std::nextafter((double)x, -INFINITY);
+  return x;
+}
 }  // namespace
 
 struct rvo3d_env {
@@ -123,6 +132,9 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   P.W = 12 + 9 * P.nm;
   P.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
   for (int k = 0; k < 3; ++k) P.map[k] = cfg->map_size[k];
+  P.T10 = sq_threshold(10.0);  // rvo_inter.py:96
+  P.T5 = sq_threshold(5.0);    // rvo_inter.py:104
+  P.T04 = sq_threshold(0.4);   // drone.py:15 goal_threshold
 
   // Launch geometry: whole envs per workgroup, about 256 threads, waves of 64.
   const int N = P.N;
@@ -140,6 +152,20 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");
   }
   P.epb = epb;
+  // zero-fill geometry: units per row of the VO region (float2 if rows are 8-B aligned)
+  P.zf_div = (uint32_t)((P.W & 1) == 0 ? (P.W - 12) / 2 : (P.W - 12));
+  P.zf_magic = 0;
+  if (P.zf_div > 0) {
+    const uint32_t m = (uint32_t)(((1ull << 32) + P.zf_div - 1) / P.zf_div);
+    bool ok = true;
+    const uint64_t qmax = (uint64_t)threads * P.zf_div;
+    for (uint64_t q = 0; q < qmax && ok; ++q) ok = ((q * m) >> 32) == q / P.zf_div;
+    if (!ok) {
+      delete h;
+      return fail(RVO3D_ERR_INVALID, "neighbors_num too large for the zero-fill index trick");
+    }
+    P.zf_magic = m;
+  }
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;

@@ -2,11 +2,21 @@
 //
 // One thread = one drone; a workgroup holds EPB whole environments so the
 // whole step (RVO reward sweep -> integrate -> observation sweep -> optional
-// auto-reset + re-observe) is ONE launch with workgroup barriers between the
-// phases.  Neighbour position / velocity / radius / priority are staged in LDS
-// (64 B per drone); the O(N^2) sweep is two-stage: a full-utilisation gate
-// loop builds a 64-bit in-range mask per lane, then only set bits run the
-// cone / time-to-collision code.
+// auto-reset + re-observe -> outputs) is ONE launch with workgroup barriers
+// between the phases.  Neighbour position / velocity / radius / priority are
+// staged in LDS (64 B per drone).
+//
+// Cost structure (fp64 VALU is the scarce resource):
+//   * gate loop: squared-distance compare against precomputed thresholds
+//     T(tau) = max{x : sqrt(x) <= tau}, exactly equivalent to the reference's
+//     `norm(..) <= tau` for a correctly rounded sqrt, builds a 64-bit in-range
+//     mask per lane at full lane utilisation;
+//   * only set bits run config_vo_circle2, and there a conservative cone
+//     pre-filter (beta >= alpha + 1e-4 rad, evaluated without asin / acos / div)
+//     rejects pairs that are surely outside the velocity obstacle; asin / acos /
+//     the TTC quadratic run only for the rest;
+//   * outputs are quantised without fp64 divisions where that is provably exact
+//     after the float32 cast, and observations are written once, coalesced.
 //
 // Decision arithmetic is fp64 and follows the reference's evaluation order
 // (compile with -ffp-contract=off; the explicit __builtin_fma calls model the
@@ -19,20 +29,25 @@
 
 namespace rvo3d {
 
-constexpr double kGoalThreshold = 0.4;   // drone.py:15
-constexpr double kNeighborGate = 10.0;   // rvo_inter.py:96
-constexpr double kBuildingGate = 5.0;    // rvo_inter.py:104
-constexpr double kCtimeThreshold = 2.0;  // rvo_inter.py:11
 constexpr double kExpRadius = 0.2;       // rvo_inter.py:11
+constexpr double kCtimeThreshold = 2.0;  // rvo_inter.py:11
 constexpr double kDeg2Rad = 0.017453292519943295;
 constexpr double kPi = 3.141592653589793;
 constexpr int kMaxThreads = 512;
+// cone pre-filter slack: inside the cone implies beta_raw <= alpha_raw (both
+// roundings to 2 decimals considered), so beta_raw >= alpha_raw + kDelta is
+// surely outside.  cos/sin of kDelta = 1e-4 rad:
+constexpr double kCosD = 0.999999995;              // cos(1e-4) rounded down
+constexpr double kSinD = 1.0000000000e-4;          // >= sin(1e-4)
 
 struct Params {
   int E, N, P, nb, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
+  uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
+  uint32_t zf_magic;  // ceil(2^32 / zf_div)
   double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
   double map[3];
+  double T10, T5, T04;  // max{x : sqrt(x) <= 10 | 5 | 0.4}  (rvo_inter.py:96,104; drone.py:15)
   // static world (SoA over EN = E*N)
   const double* wp;        // [P][3][EN]
   const int32_t* n_points; // [EN]
@@ -63,11 +78,26 @@ __device__ __forceinline__ double dot3b(double ax, double ay, double az, double 
 __device__ __forceinline__ double norm3b(double x, double y, double z) {
   return __builtin_sqrt(dot3b(x, y, z, x, y, z));
 }
-__device__ __forceinline__ double norm2b(double x, double y) {
-  return __builtin_sqrt(__builtin_fma(y, y, x * x));
+__device__ __forceinline__ double norm2sq(double x, double y) { return __builtin_fma(y, y, x * x); }
+__device__ __forceinline__ bool finite_d(double q) { return __builtin_fabs(q) < __builtin_inf(); }
+
+// np.round(x, 2) as the float32 the caller stores: float(rint(x*100)/100).
+// float(k * 0.01) == float(k / 100.0) for every integer |k| < 2^24 (k/100 is never
+// within 3e-10 relative of a float32 rounding tie, k*0.01 is within 2e-16 of it);
+// larger magnitudes take the division.
+__device__ __forceinline__ float round2_f32(double x) {
+  const double k = __builtin_rint(x * 100.0);
+  return __builtin_fabs(k) < 16777216.0 ? (float)(k * 0.01) : (float)(k / 100.0);
 }
-__device__ __forceinline__ double np_round2(double x) { return __builtin_rint(x * 100.0) / 100.0; }
-__device__ __forceinline__ double np_round3(double x) { return __builtin_rint(x * 1000.0) / 1000.0; }
+// Correctly rounded k / 1000 without a division: q = k * RN(1/1000) followed by one
+// fma residual correction (Markstein: exact for every finite k; 1000's significand
+// is not all ones).  tests/test_numeric_shortcuts.py checks it against k / 1000.0.
+__device__ __forceinline__ double k_over_1000(double k) {
+  const double q = k * 0.001;
+  const double r = __builtin_fma(-q, 1000.0, k);
+  const double c = q + r * 0.001;
+  return finite_d(k) ? c : k;
+}
 
 // Python round(x, 2): correctly rounded decimal, ties to even (vel_obs3D.py:15).
 // Returns the integer c with round(x, 2) == c / 100.0.
@@ -94,19 +124,33 @@ __device__ __forceinline__ double np_mod(double a, double b) {  // npy_divmod re
 }
 
 // ---- per-drone pieces --------------------------------------------------------
-// drone.cal_des_vel (drone.py:199-210, 340-352, 319-328)
-__device__ __forceinline__ void des_vel(const double p[3], const double cur[3], double out[3]) {
-  double dx = cur[0] - p[0], dy = cur[1] - p[1], dz = cur[2] - p[2];
-  double dis = norm3b(dx, dy, dz);
-  if (dis > kGoalThreshold) {
-    double az = atan2(dy, dx);
-    double el = atan2(dz, norm2b(dx, dy));
-    double sa, ca, se, ce;
-    sincos(az, &sa, &ca);
-    sincos(el, &se, &ce);
-    out[0] = np_round3(1.0 * (ca * ce));
-    out[1] = np_round3(1.0 * (sa * ce));
-    out[2] = np_round3(1.0 * se);
+// drone.cal_des_vel (drone.py:199-210, 340-352, 319-328): np.round(dir, 3) with
+// dir = [cos az cos el, sin az cos el, sin el].  dir equals dif/|dif| to a few
+// ulp, so when dif/|dif|*1000 is further than 1e-7 from a rounding tie the
+// rounded integers are the same and no trigonometry is needed; otherwise the
+// reference's exact sequence runs.
+__device__ __forceinline__ void des_vel(const Params& P, const double p[3], const double cur[3],
+                                        double out[3]) {
+  const double dx = cur[0] - p[0], dy = cur[1] - p[1], dz = cur[2] - p[2];
+  const double d2 = dot3b(dx, dy, dz, dx, dy, dz);
+  if (d2 > P.T04) {  // norm > goal_threshold
+    const double inv = 1000.0 / __builtin_sqrt(d2);
+    const double ux = dx * inv, uy = dy * inv, uz = dz * inv;
+    double kx = __builtin_rint(ux), ky = __builtin_rint(uy), kz = __builtin_rint(uz);
+    const double m = __builtin_fmin(__builtin_fmin(0.5 - __builtin_fabs(ux - kx),
+                                                   0.5 - __builtin_fabs(uy - ky)),
+                                    0.5 - __builtin_fabs(uz - kz));
+    if (!(m > 1e-7)) {  // near a tie (or NaN): the reference's trig sequence
+      const double az = atan2(dy, dx);
+      const double el = atan2(dz, __builtin_sqrt(norm2sq(dx, dy)));
+      double sa, ca, se, ce;
+      sincos(az, &sa, &ca);
+      sincos(el, &se, &ce);
+      kx = __builtin_rint((1.0 * (ca * ce)) * 1000.0);
+      ky = __builtin_rint((1.0 * (sa * ce)) * 1000.0);
+      kz = __builtin_rint((1.0 * se) * 1000.0);
+    }
+    out[0] = k_over_1000(kx); out[1] = k_over_1000(ky); out[2] = k_over_1000(kz);
   } else {
     out[0] = out[1] = out[2] = 0.0;
   }
@@ -125,8 +169,9 @@ __device__ __forceinline__ double deviation(const double a[3], const double b[3]
   return __builtin_sqrt(sq(p[0] - qx) + sq(p[1] - qy) + sq(p[2] - qz));
 }
 
-__device__ __forceinline__ bool arrived(const double p[3], const double d[3]) {
-  return norm3b(p[0] - d[0], p[1] - d[1], p[2] - d[2]) <= kGoalThreshold;  // drone.py:172
+__device__ __forceinline__ bool arrived(const Params& P, const double p[3], const double d[3]) {
+  const double x = p[0] - d[0], y = p[1] - d[1], z = p[2] - d[2];
+  return dot3b(x, y, z, x, y, z) <= P.T04;  // norm <= 0.4, drone.py:172
 }
 
 // vel_obs3D.cal_vo_exp_tim (vel_obs3D.py:145-182)
@@ -156,7 +201,7 @@ struct Drone {  // the 8 values a neighbour contributes (drone.dronestate[0:8])
 struct PairOut {
   bool collision, flag;
   double t, iet, md;
-  double alpha_c;  // alpha == alpha_c / 100.0
+  int alpha_c;  // alpha == alpha_c / 100.0
 };
 
 // rvo_inter.config_vo_circle2 (rvo_inter.py:116-196) + get_alpha / get_PAA /
@@ -165,40 +210,51 @@ struct PairOut {
 __device__ __forceinline__ PairOut pair_eval(const Drone& S, const Drone& O, const double a[3],
                                              int env_train) {
   PairOut o;
-  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0.0;
-  double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
-  double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
-  double R = S.r + O.r;
+  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0;
+  const double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
+  const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
+  const double R = S.r + O.r;
   if (env_train) {
     if (dis <= R) o.collision = true;
   } else {
     if (dis <= S.r - kExpRadius + O.r) o.collision = true;
   }
   if (o.collision) return o;
-  double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
+  const double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
   if (dotp <= 0) return o;
-  double nab = norm3b(rx, ry, rz);
-  o.alpha_c = py_round2_c(asin(R / nab));
-  double pr = S.prio / (S.prio + O.prio);
-  double paax = pr * (2 * S.x + (S.vx + O.vx));
-  double paay = pr * (2 * S.y + (S.vy + O.vy));
-  double paaz = pr * (2 * S.z + (S.vz + O.vz));
-  double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay, wz = (S.z + 2 * a[2]) - paaz;
-  double dp = dot3b(rx, ry, rz, wx, wy, wz);
-  double AB = nab * norm3b(wx, wy, wz);
-  double cosang = (AB != 0) ? dp / AB : 0.0;
-  double beta = np_round2(acos(cosang));  // NaN when |cos| > 1 (np.arccos)
-  double t = __builtin_inf();
-  if (o.alpha_c / 100.0 > beta) {
-    double rvx = 2 * a[0] - O.vx - S.vx, rvy = 2 * a[1] - O.vy - S.vy,
-           rvz = 2 * a[2] - O.vz - S.vz;
-    t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, O.r);
-    if (t < kCtimeThreshold) o.flag = true;
-    else t = __builtin_inf();
+  // get_PAA (vel_obs3D.py:19-32); x / (x + x) == 0.5 exactly
+  const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
+  const double paax = pr * (2 * S.x + (S.vx + O.vx));
+  const double paay = pr * (2 * S.y + (S.vy + O.vy));
+  const double paaz = pr * (2 * S.z + (S.vz + O.vz));
+  const double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay,
+               wz = (S.z + 2 * a[2]) - paaz;
+  const double dp = dot3b(rx, ry, rz, wx, wy, wz);
+  // dp <= 0: cos <= 0 (or AB == 0 -> cos := 0), beta >= pi/2, beta_c >= 157 >= alpha_c: outside
+  if (dp <= 0) return o;
+  const double d2 = dot3b(rx, ry, rz, rx, ry, rz);  // np.linalg.norm(pb - pa) ** 2
+  const double w2 = dot3b(wx, wy, wz, wx, wy, wz);
+  // Conservative pre-filter.  Inside needs alpha_c >= beta_c + 1, which implies
+  // beta_raw <= alpha_raw; so cos(beta) < cos(alpha + 1e-4) is surely outside.
+  // |ab| cos(alpha + d) = cos d sqrt(d2 - R^2) - sin d R =: K, cos(beta) = dp / (|ab| |w|).
+  const double K = kCosD * __builtin_sqrt(d2 - R * R) - kSinD * R;
+  if (K > 0 && dp * dp < (w2 * (K * K)) * (1.0 - 1e-9)) return o;
+  const double nab = __builtin_sqrt(d2);
+  const double alpha_c = py_round2_c(asin(R / nab));
+  const double AB = nab * __builtin_sqrt(w2);
+  const double cosang = (AB != 0) ? dp / AB : 0.0;
+  const double beta_c = __builtin_rint(acos(cosang) * 100.0);  // NaN when |cos| > 1 (np.arccos)
+  if (!(alpha_c > beta_c)) return o;  // alpha > beta on the rounded values (rvo_inter.py:226)
+  const double rvx = 2 * a[0] - O.vx - S.vx, rvy = 2 * a[1] - O.vy - S.vy,
+               rvz = 2 * a[2] - O.vz - S.vz;
+  const double t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, O.r);
+  if (t < kCtimeThreshold) {
+    o.flag = true;
+    o.t = t;
+    o.iet = 1 / (t + 0.2);
+    o.md = dis - O.r;
+    o.alpha_c = (int)alpha_c;
   }
-  o.t = t;
-  o.iet = 1 / (t + 0.2);
-  o.md = dis - O.r;
   return o;
 }
 
@@ -207,6 +263,7 @@ struct Lds {
   double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T]
   double* iet;                                   // [nm][T] kept VO rows, ascending urgency
   uint32_t* pk;                                  // [nm][T] (alpha_c << 16) | j
+  int* kept;                                     // [T] rows kept by the final sweep
   int* any_reset;                                // [epb]
   int T;
 };
@@ -218,12 +275,13 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
   L.r = d + 6 * T; L.prio = d + 7 * T;
   L.iet = d + 8 * T;
   L.pk = reinterpret_cast<uint32_t*>(L.iet + (size_t)nm * T);
-  L.any_reset = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
+  L.kept = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
+  L.any_reset = L.kept + T;
   L.T = T;
   return L;
 }
 __host__ __device__ inline size_t lds_bytes(int T, int nm, int epb) {
-  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)epb * 4 + 16;
+  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 4 + (size_t)epb * 4 + 16;
 }
 
 __device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
@@ -257,12 +315,14 @@ __device__ __forceinline__ int sweep(const Params& P, const Lds& L, int tid, int
   for (int c0 = 0; c0 < N; c0 += 64) {
     const int cn = (N - c0) < 64 ? (N - c0) : 64;
     unsigned long long mask = 0ull;
-    for (int jj = 0; jj < cn; ++jj) {  // gate: full lane utilisation
+    for (int jj = 0; jj < cn; ++jj) {  // gate: full lane utilisation, no sqrt
       const int k = lbase + c0 + jj;
-      const double ox = L.x[k], oy = L.y[k], oz = L.z[k];
-      const bool same = (S.x == ox) && (S.y == oy) && (S.z == oz);  // rvo_inter.py:92
-      const double dist = norm3b(S.x - ox, S.y - oy, S.z - oz);
-      if (!same && dist <= kNeighborGate) mask |= (1ull << jj);
+      const double dx = S.x - L.x[k], dy = S.y - L.y[k], dz = S.z - L.z[k];
+      const double d2 = dot3b(dx, dy, dz, dx, dy, dz);
+      // norm <= 10 (rvo_inter.py:96) and not the same position (rvo_inter.py:92):
+      // d2 == 0 with a non-zero difference needs |dif| < 1e-154, handled exactly anyway
+      const bool in = (d2 <= P.T10) && (d2 > 0.0 || dx != 0.0 || dy != 0.0 || dz != 0.0);
+      if (in) mask |= (1ull << jj);
     }
     while (mask) {  // only in-range neighbours
       const int jj = __builtin_ctzll(mask);
@@ -319,7 +379,7 @@ __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
     const double bx = P.bld[4 * b], by = P.bld[4 * b + 1], bh = P.bld[4 * b + 2],
                  br = P.bld[4 * b + 3];
     if (bh > S.z - 2) {
-      if (norm2b(S.x - bx, S.y - by) <= kBuildingGate) {
+      if (norm2sq(S.x - bx, S.y - by) <= P.T5) {  // norm <= 5
         if (S.z <= bh) {
           double dis = __builtin_sqrt(sq(S.x - bx) + sq(S.y - by));
           if (dis <= S.r + br) hit = true;
@@ -330,25 +390,34 @@ __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
   return hit;
 }
 
-// Writes one observation row: np.round(concat[12 proprio, kept VO rows], 2)
-// (ir_gym.py:208-229 / :353-355), zero padded to 12 + 9*nm floats.
-__device__ __forceinline__ void write_obs(const Params& P, const Lds& L, int tid, int lbase,
-                                          int g, const Drone& S, const double dv[3],
-                                          double dev, int kept) {
+// Per-lane part of one observation row: np.round(concat[12 proprio, kept VO
+// rows], 2) (ir_gym.py:208-229 / :353-355).  The zero padding behind the kept
+// rows is written by zero_fill() cooperatively.
+__device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int tid, int lbase,
+                                              int g, const Drone& S, const double dv[3],
+                                              double dev, int kept) {
   float* o = P.obs + (size_t)g * P.W;
+  const double v[12] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio, dv[0], dv[1], dv[2], dev};
+  float f[12];
   bool bad = false;
-  double v[12] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio, dv[0], dv[1], dv[2], dev};
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    double q = np_round2(v[k]);
-    bad |= !(__builtin_fabs(q) < __builtin_inf());
-    o[k] = (float)q;
+    f[k] = round2_f32(v[k]);
+    bad |= !finite_d(v[k]);
+  }
+  if ((P.W & 1) == 0) {  // rows are 8-B aligned
+    float2* o2 = reinterpret_cast<float2*>(o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o2[k] = make_float2(f[2 * k], f[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = f[k];
   }
   for (int s = 0; s < kept; ++s) {
     const uint32_t pk = L.pk[s * L.T + tid];
     const int j = (int)(pk & 0xffffu);
     const Drone O = lds_drone(L, lbase + j);
-    const double pr = S.prio / (S.prio + O.prio);
+    const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
     double row[9];
     row[0] = pr * (2 * S.x + (S.vx + O.vx));  // get_PAA, vel_obs3D.py:19-32
     row[1] = pr * (2 * S.y + (S.vy + O.vy));
@@ -359,14 +428,41 @@ __device__ __forceinline__ void write_obs(const Params& P, const Lds& L, int tid
     row[8] = L.iet[s * L.T + tid];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      double q = np_round2(row[k]);
-      bad |= !(__builtin_fabs(q) < __builtin_inf());
-      o[12 + 9 * s + k] = (float)q;
+      bad |= !finite_d(row[k]);
+      o[12 + 9 * s + k] = round2_f32(row[k]);
     }
   }
-  for (int k = 12 + 9 * kept; k < P.W; ++k) o[k] = 0.0f;
+  // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
+  if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
   P.vo_count[g] = kept;
   if (bad) atomicOr(P.err, 1u);
+}
+
+// Cooperative, coalesced zero padding of the VO region of every row of this
+// workgroup: rows [row0, row0 + nrows) are contiguous in memory; L.kept holds
+// the kept count per row.  Unit = float2 when W is even (rows 8-B aligned),
+// float otherwise.
+__device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid, int row0,
+                                          int nrows) {
+  const uint32_t per_row = P.zf_div;
+  if (per_row == 0) return;
+  const uint32_t total = (uint32_t)nrows * per_row;
+  float* base = P.obs + (size_t)row0 * P.W + 12;
+  if ((P.W & 1) == 0) {
+    for (uint32_t q = tid; q < total; q += L.T) {
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.zf_magic) >> 32);
+      const uint32_t c = q - row * per_row;       // float2 index inside the VO region
+      const uint32_t first = (9u * (uint32_t)L.kept[row] + 1u) >> 1;  // first all-zero unit
+      if (c >= first)
+        *reinterpret_cast<float2*>(base + (size_t)row * P.W + 2 * c) = make_float2(0.f, 0.f);
+    }
+  } else {
+    for (uint32_t q = tid; q < total; q += L.T) {
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.zf_magic) >> 32);
+      const uint32_t c = q - row * per_row;
+      if (c >= 9u * (uint32_t)L.kept[row]) base[(size_t)row * P.W + c] = 0.0f;
+    }
+  }
 }
 
 __device__ __forceinline__ void load_wp(const Params& P, int g, int k, double out[3]) {
@@ -376,42 +472,51 @@ __device__ __forceinline__ void load_wp(const Params& P, int g, int k, double ou
   out[2] = P.wp[((size_t)k * 3 + 2) * EN + g];
 }
 
-// ir_gym.rvo_reward_cal (ir_gym.py:64-133) after config_vo_reward
-__device__ __forceinline__ double rvo_reward(const double dv[3], const double a[3], bool flag,
-                                             double tmin) {
-  const double d0 = np_round3(dv[0]), d1 = np_round3(dv[1]), d2 = np_round3(dv[2]);
+// ir_gym.rvo_reward_cal (ir_gym.py:64-133) after config_vo_reward.  Returns the
+// integer k with np.round(total, 3) == k / 1000 (or inf / nan, survey Q9).
+__device__ __forceinline__ double rvo_reward_k(const double dv[3], const double a[3], bool flag,
+                                               double tmin) {
+  // des_vel is already a 3-decimal value: np.round(., 3) again is the identity
+  const double d0 = dv[0], d1 = dv[1], d2 = dv[2];
   const double vel_penalty = 0.2 * norm3b(a[0], a[1], a[2]) / norm3b(d0, d1, d2);
   const double eps = 1e-8;
   const double magA = __builtin_sqrt(sq(d0) + sq(d1) + sq(d2) + eps);
   const double magB = __builtin_sqrt(sq(a[0]) + sq(a[1]) + sq(a[2]) + eps);
   const double dotp = d0 * a[0] + d1 * a[1] + d2 * a[2];
-  double ang;
-  if (magA < 1e-6 || magB < 1e-6) ang = 0.0;
-  else {
-    double c = dotp / (magA * magB);
-    c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c);
-    ang = acos(c);
-  }
+  double c = dotp / (magA * magB);  // magA, magB >= 1e-4: the `< 1e-6` branch is dead
+  c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c);
+  // angle bins (ir_gym.py:91-100) on ang = acos(c): compare c with the cosines of
+  // the bin edges; acos itself only when c is within 1e-12 of an edge.
+  const double C18 = 0.984807753012208, C6 = 0.8660254037844387, C3 = 0.5000000000000001,
+               C2 = 6.123233995736766e-17;
   double punish;
-  if (-kPi / 18 < ang && ang < kPi / 18) punish = 3;
-  else if (-kPi / 6 < ang && ang < kPi / 6) punish = 1;
-  else if (-kPi / 3 < ang && ang < kPi / 3) punish = 0.5;
-  else if (-kPi / 2 < ang && ang < kPi / 2) punish = 0;
-  else punish = -4;
+  if (c == 0.0) punish = -4;  // acos(0) == pi/2 exactly: not < pi/2
+  else if (__builtin_fabs(c - C18) > 1e-12 && __builtin_fabs(c - C6) > 1e-12 &&
+           __builtin_fabs(c - C3) > 1e-12 && __builtin_fabs(c - C2) > 1e-12) {
+    punish = c > C18 ? 3 : (c > C6 ? 1 : (c > C3 ? 0.5 : (c > C2 ? 0 : -4)));
+    if (c != c) punish = -4;
+  } else {
+    const double ang = acos(c);
+    if (ang < kPi / 18) punish = 3;
+    else if (ang < kPi / 6) punish = 1;
+    else if (ang < kPi / 3) punish = 0.5;
+    else if (ang < kPi / 2) punish = 0;
+    else punish = -4;
+  }
   double safety = 0;
   if (flag) {
     double urgency = 0;
     if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
     safety = -2.5 + urgency;
   }
-  return np_round3(punish + vel_penalty + safety);
+  return __builtin_rint((punish + vel_penalty + safety) * 1000.0);
 }
 
-// ir_gym.mov_reward (ir_gym.py:256-311)
-__device__ __forceinline__ double mov_reward(const Params& P, bool collision, bool arrive_r,
-                                             int waypoint_num, int n_points_m1, bool dest_r,
-                                             double dev, bool len_flag, double exlen) {
-  if (collision) return -50.0;
+// ir_gym.mov_reward (ir_gym.py:256-311); returns k with round(., 3) == k / 1000
+__device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, bool arrive_r,
+                                               int waypoint_num, int n_points_m1, bool dest_r,
+                                               double dev, bool len_flag, double exlen) {
+  if (collision) return -50000.0;  // -50
   double reward = 0;
   if (arrive_r) reward += 3.0 * P.pow95[n_points_m1 - waypoint_num];
   if (dest_r) reward += 20.0;
@@ -422,7 +527,13 @@ __device__ __forceinline__ double mov_reward(const Params& P, bool collision, bo
     ex_pen = -0.3 * log(exlen + 1 + 1e-6);
     if (ex_pen < -6 || ex_pen != ex_pen) ex_pen = -6;
   }
-  return np_round3(reward + dev_pen + ex_pen);
+  return __builtin_rint((reward + dev_pen + ex_pen) * 1000.0);
+}
+
+// mdin.py:28 adds two np.round(., 3) values in fp64; k / 1000 is formed exactly
+// (k_over_1000) so the sum, cancellation included, is the reference's double.
+__device__ __forceinline__ float reward_f32(double k1, double k2) {
+  return (float)(k_over_1000(k1) + k_over_1000(k2));
 }
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
@@ -435,14 +546,16 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
   const Lds L = carve_lds(smem, T, P.nm, P.epb);
   const int el = tid / N;
   const int d = tid - el * N;
-  const int e = blockIdx.x * P.epb + el;
+  const int e0 = blockIdx.x * P.epb;
+  const int e = e0 + el;
   const bool active = (el < P.epb) && (e < P.E);
   const int g = active ? e * N + d : 0;
   const int lbase = el * N;
+  const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
 
   double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
   double yaw = 0, pitch = 0, real_len = 0, max_dev = 0, extra_len = 0, route_len = 0;
-  double cur[3] = {0, 0, 0}, prev[3] = {0, 0, 0}, dst[3] = {0, 0, 0}, dv[3], dev = 0;
+  double cur[3] = {0, 0, 0}, prev[3] = {0, 0, 0}, dst[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dev = 0;
   int wpi = 1, npts = 2;
   bool f_arrive = false, f_dest = false;
   Drone S;
@@ -476,11 +589,12 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
       }
     }
     // drone.dronestate on the pre-move state (drone.py:254-263)
-    des_vel(p, cur, dv);
+    des_vel(P, p, cur, dv);
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
   }
   if (tid < P.epb) L.any_reset[tid] = 0;
+  L.kept[tid] = 0;
   L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
   L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
   L.r[tid] = S.r; L.prio[tid] = S.prio;
@@ -494,19 +608,22 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
   if (MODE == kObserve) {
     if (active) {
       const int kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, collision);
-      write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
+      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+      L.kept[tid] = kept;
       P.max_dev[g] = max_dev;
     }
+    __syncthreads();
+    zero_fill(P, L, tid, e0 * N, nrows);
     return;
   }
 
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
   if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
-  double rew = 0;
+  double rew_k = 0;
   if (active) {
     sweep<false>(P, L, tid, lbase, S, az, flag, tmin, collision);
-    rew = rvo_reward(dv, a, flag, tmin);
+    rew_k = rvo_reward_k(dv, a, flag, tmin);
   }
   __syncthreads();  // everyone is done with the pre-move LDS image
 
@@ -520,17 +637,19 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     speed = (0.0 > nv) ? 0.0 : nv;
     yaw = np_mod(yaw + dyaw, 360.0);
     pitch = clampd(pitch + dpit, -90.0, 90.0);
-    double sy, cy, sp, cp;
-    sincos(yaw * kDeg2Rad, &sy, &cy);
-    sincos(pitch * kDeg2Rad, &sp, &cp);
-    double nvx = speed * cp * cy, nvy = speed * cp * sy, nvz = speed * sp;
-    if (f_dest) nvx = nvy = nvz = 0.0;  // `stop` := map_size (env_base.py:142, drone.py:107)
+    double nvx = 0.0, nvy = 0.0, nvz = 0.0;
+    if (!f_dest) {  // `stop` := map_size (env_base.py:142, drone.py:107): parked once finished
+      double sy, cy, sp, cp;
+      sincos(yaw * kDeg2Rad, &sy, &cy);
+      sincos(pitch * kDeg2Rad, &sp, &cp);
+      nvx = speed * cp * cy; nvy = speed * cp * sy; nvz = speed * sp;
+    }
     const double q0 = p[0], q1 = p[1], q2 = p[2];
     p[0] = p[0] + nvx; p[1] = p[1] + nvy; p[2] = p[2] + nvz;
     v[0] = nvx; v[1] = nvy; v[2] = nvz;
     real_len = real_len + norm3b(p[0] - q0, p[1] - q1, p[2] - q2);
-    if (arrived(p, cur)) {  // drone.py:116-129
-      bool at_dst = arrived(p, dst);
+    if (arrived(P, p, cur)) {  // drone.py:116-129
+      const bool at_dst = arrived(P, p, dst);
       if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
       if (!at_dst && wpi < npts - 1) {
         wpi += 1;
@@ -540,7 +659,7 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
       }
     }
     // dronestate on the post-move state
-    des_vel(p, cur, dv);
+    des_vel(P, p, cur, dv);
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
   }
@@ -551,12 +670,13 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
 
   // ---- sweep B: ir_gym.observation_reward on the post-move state (ir_gym.py:156-254)
   bool do_reset = false;
+  int kept = 0;
   if (active) {
     bool arrive_r = false, dest_r = false;
     const int waypoint_num = wpi;
-    if (arrived(p, cur) && !f_arrive) { f_arrive = true; arrive_r = true; }
+    if (!f_arrive && arrived(P, p, cur)) { f_arrive = true; arrive_r = true; }
     if (f_arrive) {
-      if (arrived(p, dst)) {
+      if (arrived(P, p, dst)) {
         extra_len = real_len - route_len;
         if (!f_dest) { f_dest = true; dest_r = true; }
       }
@@ -564,14 +684,13 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     const double exlen = real_len - route_len + 4;
     const bool len_flag = exlen > 0;
     collision = building_hit(P, S);
-    const int kept = sweep<true>(P, L, tid, lbase, S, az, flag, tmin, collision);
+    kept = sweep<true>(P, L, tid, lbase, S, az, flag, tmin, collision);
     if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
         p[2] > P.map[2])
       collision = true;  // drone.drone_out_map, drone.py:213-225
-    write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
-    const double mr = mov_reward(P, collision, arrive_r, waypoint_num, npts - 1, dest_r, dev,
-                                 len_flag, exlen);
-    P.reward[g] = (float)(rew + mr);  // mdin.py:28
+    const double mr_k = mov_reward_k(P, collision, arrive_r, waypoint_num, npts - 1, dest_r,
+                                     dev, len_flag, exlen);
+    P.reward[g] = reward_f32(rew_k, mr_k);  // mdin.py:28
     P.done[g] = collision ? 1 : 0;
     P.info[g] = f_arrive ? 1 : 0;
     P.finish[g] = f_dest ? 1 : 0;
@@ -583,6 +702,10 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     if (do_reset) L.any_reset[el] = 1;
     __syncthreads();  // sweep B reads done; any_reset visible
     const bool env_reset = active && (L.any_reset[el] != 0);
+    if (active && !env_reset) {  // this env keeps the step's observation: write it now
+      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+      L.kept[tid] = kept;
+    }
     if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
       load_wp(P, g, 0, p);
       v[0] = v[1] = v[2] = 0.0;
@@ -590,7 +713,7 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
       real_len = 0.0; max_dev = 0.0; yaw = 0.0; pitch = 0.0;
       load_wp(P, g, 1, cur);
       prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2];
-      des_vel(p, cur, dv);
+      des_vel(P, p, cur, dv);
       dev = deviation(prev, cur, p);
       if (dev > max_dev) max_dev = dev;
       L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
@@ -600,9 +723,13 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     if (env_reset) {  // ir_gym.env_observation for the whole env (ir_gym.py:372-383)
       S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
       bool c2 = false;
-      const int kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, c2);
-      write_obs(P, L, tid, lbase, g, S, dv, dev, kept);
+      kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, c2);
+      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+      L.kept[tid] = kept;
     }
+  } else if (active) {
+    write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+    L.kept[tid] = kept;
   }
 
   if (active) {
@@ -613,6 +740,8 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     P.wp_idx[g] = wpi;
     P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
   }
+  __syncthreads();  // L.kept complete
+  zero_fill(P, L, tid, e0 * N, nrows);
 }
 
 // ---- small state kernels -------------------------------------------------------
@@ -635,7 +764,7 @@ __global__ void des_vel_kernel(const Params P, double* out) {
   if (g >= P.E * P.N) return;
   double p[3] = {P.px[g], P.py[g], P.pz[g]}, cur[3], dv[3];
   load_wp(P, g, P.wp_idx[g], cur);
-  des_vel(p, cur, dv);
+  des_vel(P, p, cur, dv);
   out[3 * (size_t)g] = dv[0]; out[3 * (size_t)g + 1] = dv[1]; out[3 * (size_t)g + 2] = dv[2];
 }
 

@@ -227,3 +227,33 @@ def test_nonfinite_observation_sets_error_flag():
     with pytest.raises(ValueError):
         env.check_finite()
     env.close()
+
+
+def test_mdin_list_api_config1_world4():
+    """BASELINE config 1 plumbing: the `mdin` list API (mdin.py:7-48) on world_4,
+    driven exactly like uaisa_env/gym_env_test.py:7-21, against the golden run."""
+    from rvo3d_amd.drone_envs.mdin import mdin
+    fx = load([f for f in FILES if f.endswith("world_4_desvel.npz")][0])
+    world = dict(drone_num=4, map_size=fx["map_size"].tolist(),
+                 waypoints_list=fx["waypoints"].tolist(), n_points_list=fx["n_points"].tolist(),
+                 building_list=[])
+    env = mdin(world=world)
+    obs_list = env.drone_reset(False)
+    assert len(obs_list) == 4 and all(len(o) == 21 for o in obs_list)
+    assert env.ir_gym.drone_num == 4 and env.observation_space.shape == (21,)
+    for t in range(fx["actions"].shape[0]):
+        vel_list = env.ir_gym.cal_des_list()
+        np.testing.assert_array_equal(np.asarray(vel_list), fx["actions"][t])
+        obs_list, reward_list, done_list, info_list, finish_list = env.drone_step(vel_list)
+        assert done_list == [bool(x) for x in fx["done"][t]]
+        assert finish_list == [bool(x) for x in fx["finish"][t]]
+        for i, o in enumerate(obs_list):
+            k = max(int(fx["vo_count"][t][i]), 1)
+            assert len(o) == 12 + 9 * k
+            assert close(o, fx["obs"][t][i][:len(o)]).all()
+        assert close(np.asarray(reward_list), fx["reward"][t]).all()
+        for i in [i for i, d in enumerate(done_list) if d]:
+            env.drone_reset_one(False, i)
+    with pytest.raises(AssertionError):
+        env.drone_step([[0, 0, 0]] * 4)   # python lists are rejected (drone.py:98-101)
+    env.close()

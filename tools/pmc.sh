@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage: tools/pmc.sh <tag> [bench args...]   (run on the GPU box from the repo root)
+# Collects PMC counters for bench.py in separate passes (no tracing flags mixed in).
+set -u
+TAG=$1; shift
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for CTRS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+            "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_THREAD_CYCLES_VALU" \
+            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout -k 10 200 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed" >> $OUT/fail.log
+done
+python3 - <<PY
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "env_kernel<2>" in r["Kernel_Name"]:
+            a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+with open("$OUT/summary.txt", "w") as o:
+    for k, (v, n) in sorted(agg.items()):
+        o.write(f"{k} per-launch {v / n:.6g} over {n} launches\n")
+print(open("$OUT/summary.txt").read())
+PY
