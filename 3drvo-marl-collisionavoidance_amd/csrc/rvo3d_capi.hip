@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -98,7 +99,12 @@ int check(rvo3d_env* h, bool need_world) {
 
 template <int MODE>
 int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
-  hipLaunchKernelGGL(rvo3d::env_kernel<MODE>, dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+  if (P.wave_mode)
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, true>), dim3(h->blocks), dim3(h->threads), h->lds,
+                       s, P);
+  else
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, false>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
 }
@@ -130,22 +136,56 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   P.E = cfg->num_envs; P.N = cfg->num_drones; P.P = cfg->max_points;
   P.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
   P.W = 12 + 9 * P.nm;
+  if (const char* ab = std::getenv("RVO3D_ABLATE")) P.ablate = std::atoi(ab);  // diagnostics only
   P.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
   for (int k = 0; k < 3; ++k) P.map[k] = cfg->map_size[k];
   P.T10 = sq_threshold(10.0);  // rvo_inter.py:96
   P.T5 = sq_threshold(5.0);    // rvo_inter.py:104
   P.T04 = sq_threshold(0.4);   // drone.py:15 goal_threshold
+  {
+    // fp32 candidate filter (stage G).  Coordinates are centred on the map and
+    // assumed within cmax of it (envs with a drone further out bypass the filter).
+    // u = 2^-24.  A centred coordinate carries <= u*cmax of rounding, a difference
+    // of two <= eD = u*(2*cmax + 2*10.5); a squared distance at |d| <= 10.5 is off by
+    // <= 2*sqrt(3)*10.5*eD + 3*eD^2 + 8u*10.5^2; v.rel by <= |v|_1*(eD + 4u*10.5).
+    // Every band below is twice its bound.
+    double mx = std::fmax(P.map[0], std::fmax(P.map[1], P.map[2]));
+    if (!(mx > 0)) mx = 1.0;
+    for (int k = 0; k < 3; ++k) P.cen[k] = 0.5 * P.map[k];
+    const double cmax = 0.75 * mx + 16.0;
+    const double u = std::ldexp(1.0, -24);
+    const double eD = u * (2.0 * cmax + 21.0);
+    const double band = 2.0 * (2.0 * 1.7320508 * 10.5 * eD + 3.0 * eD * eD + 8.0 * u * 110.25);
+    P.cmax = (float)cmax;
+    P.band = std::nextafter((float)band, INFINITY);
+    P.t10f = std::nextafter((float)(P.T10 + band), INFINITY);
+    P.kdot = std::nextafter((float)(2.0 * (eD + 4.0 * u * 10.5) * 1.001), INFINITY);
+    // stage X1 (wave mode).  With gap = d^2 - R^2 >= x1_gap = 512*band the relative
+    // error of gap is <= 1/1024 and |rel| >= sqrt(gap); a direction cosine then
+    // carries <= cs = 4*(sqrt(3)*eD/sqrt(gap) + 8u) of error.  K^2 is compared with
+    // slack 1 - (4e-3 + 4*cs): 2e-3 for gap's error, the rest for dp, w2 and K.
+    const double gap = 512.0 * band;
+    const double cs = 4.0 * (1.7320508 * eD / std::sqrt(gap) + 8.0 * u);
+    P.x1_gap = (float)gap;
+    P.x1_k2 = (float)(1.0 - (4e-3 + 4.0 * cs));
+    const double cs_out = cs > 1e-3 ? cs : 1e-3;
+    P.x1_cs2 = (float)(cs_out * cs_out);
+  }
 
-  // Launch geometry: whole envs per workgroup, about 256 threads, waves of 64.
+  // Launch geometry: whole envs per workgroup.  When envs do not straddle waves
+  // (N divides 64) a workgroup is ONE wave: its barriers are free and every wave
+  // is scheduled independently; otherwise about 256 threads, waves of 64.
   const int N = P.N;
+  P.wave_mode = (N <= 64 && !std::getenv("RVO3D_GENERIC")) ? 1 : 0;
   int epb = N >= 256 ? 1 : 256 / N;
+  if (P.wave_mode) epb = 64 / N;  // whole envs inside one wave; idle lanes when 64 % N != 0
   if (epb > P.E) epb = P.E;
-  int threads = (int)align_up((size_t)epb * N, 64);
-  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb);
-  while (lds > 64 * 1024 && epb > 1) {  // keep >= 2 workgroups per CU where possible
+  int threads = P.wave_mode ? 64 : (int)align_up((size_t)epb * N, 64);
+  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, P.wave_mode);
+  while (!P.wave_mode && lds > 64 * 1024 && epb > 1) {  // keep >= 2 workgroups per CU
     epb = (epb + 1) / 2;
     threads = (int)align_up((size_t)epb * N, 64);
-    lds = rvo3d::lds_bytes(threads, P.nm, epb);
+    lds = rvo3d::lds_bytes(threads, P.nm, epb, false);
   }
   if (lds > 160 * 1024) {
     delete h;
@@ -170,12 +210,22 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;
   if (lds > 64 * 1024) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1, e2, e3;
+    if (P.wave_mode) {
+      e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    } else {
+      e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
       delete h;
       return fail(RVO3D_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");

@@ -7,14 +7,16 @@
 // staged in LDS (64 B per drone).
 //
 // Cost structure (fp64 VALU is the scarce resource):
-//   * gate loop: squared-distance compare against precomputed thresholds
-//     T(tau) = max{x : sqrt(x) <= tau}, exactly equivalent to the reference's
-//     `norm(..) <= tau` for a correctly rounded sqrt, builds a 64-bit in-range
-//     mask per lane at full lane utilisation;
-//   * only set bits run config_vo_circle2, and there a conservative cone
-//     pre-filter (beta >= alpha + 1e-4 rad, evaluated without asin / acos / div)
-//     rejects pairs that are surely outside the velocity obstacle; asin / acos /
-//     the TTC quadratic run only for the rest;
+//   * stage G (packed fp32, full lane utilisation): a CONSERVATIVE candidate
+//     filter over all neighbours - in range (|dp|^2 <= 100 + band), approaching
+//     (v.rel > -eps) or nearly touching - builds a 64-bit candidate mask per
+//     lane.  The bands bound the fp32 error (host-computed from the map size),
+//     so a pair the reference would act on is never dropped;
+//   * stage X (fp64, candidates only) repeats every test exactly: squared norms
+//     against T(tau) = max{x : sqrt(x) <= tau} (equivalent to the reference's
+//     `norm(..) <= tau` for a correctly rounded sqrt), collision, v.rel, then a
+//     conservative cone pre-filter (beta >= alpha + 1e-4 rad, no asin/acos/div)
+//     and only for the rest asin / acos / the TTC quadratic;
 //   * outputs are quantised without fp64 divisions where that is provably exact
 //     after the float32 cast, and observations are written once, coalesced.
 //
@@ -43,11 +45,23 @@ constexpr double kSinD = 1.0000000000e-4;          // >= sin(1e-4)
 struct Params {
   int E, N, P, nb, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
+  int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
   double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
   double map[3];
   double T10, T5, T04;  // max{x : sqrt(x) <= 10 | 5 | 0.4}  (rvo_inter.py:96,104; drone.py:15)
+  // fp32 candidate filter (stage G): centre, coordinate bound and error bands
+  double cen[3];
+  float cmax;      // |centred coordinate| bound the bands were computed for
+  float t10f;      // T10 + band, rounded up
+  float band;      // fp32 error bound of a squared distance at <= 10.5 m
+  float kdot;      // fp32 error bound of v.rel per unit |v|_1
+  // wave mode (N <= 64, one wave per workgroup): fp32 cone pre-filter (stage X1)
+  int wave_mode;
+  float x1_gap;    // below this d2 - R^2 the cone filter is skipped (pair passes)
+  float x1_k2;     // slack factor on K^2
+  float x1_cs2;    // (cos-space error bound)^2: dp < 0 and dp^2 > cs2*d2*w2 is surely outside
   // static world (SoA over EN = E*N)
   const double* wp;        // [P][3][EN]
   const int32_t* n_points; // [EN]
@@ -204,60 +218,6 @@ struct PairOut {
   int alpha_c;  // alpha == alpha_c / 100.0
 };
 
-// rvo_inter.config_vo_circle2 (rvo_inter.py:116-196) + get_alpha / get_PAA /
-// vo_out_jud_vector / get_beta (vel_obs3D.py:8-66, rvo_inter.py:212-228).
-// `a` is the action after the "< 1e-5 -> 0" rule (rvo_inter.py:118).
-__device__ __forceinline__ PairOut pair_eval(const Drone& S, const Drone& O, const double a[3],
-                                             int env_train) {
-  PairOut o;
-  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0;
-  const double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
-  const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
-  const double R = S.r + O.r;
-  if (env_train) {
-    if (dis <= R) o.collision = true;
-  } else {
-    if (dis <= S.r - kExpRadius + O.r) o.collision = true;
-  }
-  if (o.collision) return o;
-  const double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
-  if (dotp <= 0) return o;
-  // get_PAA (vel_obs3D.py:19-32); x / (x + x) == 0.5 exactly
-  const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
-  const double paax = pr * (2 * S.x + (S.vx + O.vx));
-  const double paay = pr * (2 * S.y + (S.vy + O.vy));
-  const double paaz = pr * (2 * S.z + (S.vz + O.vz));
-  const double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay,
-               wz = (S.z + 2 * a[2]) - paaz;
-  const double dp = dot3b(rx, ry, rz, wx, wy, wz);
-  // dp <= 0: cos <= 0 (or AB == 0 -> cos := 0), beta >= pi/2, beta_c >= 157 >= alpha_c: outside
-  if (dp <= 0) return o;
-  const double d2 = dot3b(rx, ry, rz, rx, ry, rz);  // np.linalg.norm(pb - pa) ** 2
-  const double w2 = dot3b(wx, wy, wz, wx, wy, wz);
-  // Conservative pre-filter.  Inside needs alpha_c >= beta_c + 1, which implies
-  // beta_raw <= alpha_raw; so cos(beta) < cos(alpha + 1e-4) is surely outside.
-  // |ab| cos(alpha + d) = cos d sqrt(d2 - R^2) - sin d R =: K, cos(beta) = dp / (|ab| |w|).
-  const double K = kCosD * __builtin_sqrt(d2 - R * R) - kSinD * R;
-  if (K > 0 && dp * dp < (w2 * (K * K)) * (1.0 - 1e-9)) return o;
-  const double nab = __builtin_sqrt(d2);
-  const double alpha_c = py_round2_c(asin(R / nab));
-  const double AB = nab * __builtin_sqrt(w2);
-  const double cosang = (AB != 0) ? dp / AB : 0.0;
-  const double beta_c = __builtin_rint(acos(cosang) * 100.0);  // NaN when |cos| > 1 (np.arccos)
-  if (!(alpha_c > beta_c)) return o;  // alpha > beta on the rounded values (rvo_inter.py:226)
-  const double rvx = 2 * a[0] - O.vx - S.vx, rvy = 2 * a[1] - O.vy - S.vy,
-               rvz = 2 * a[2] - O.vz - S.vz;
-  const double t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, O.r);
-  if (t < kCtimeThreshold) {
-    o.flag = true;
-    o.t = t;
-    o.iet = 1 / (t + 0.2);
-    o.md = dis - O.r;
-    o.alpha_c = (int)alpha_c;
-  }
-  return o;
-}
-
 // ---- LDS views ---------------------------------------------------------------
 struct Lds {
   double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T]
@@ -265,10 +225,18 @@ struct Lds {
   uint32_t* pk;                                  // [nm][T] (alpha_c << 16) | j
   int* kept;                                     // [T] rows kept by the final sweep
   int* any_reset;                                // [epb]
-  int T;
+  int* far;                                      // [epb] a drone is outside the fp32 filter's bound
+  float *fx, *fy, *fz, *fr;                      // [epb * Npad] centred x, y, z, radius in fp32
+  int T, Npad;                                   // Npad = N rounded up to even (8-B pair reads)
+  // wave mode: fp32 image, each env's N slots stored twice ([el][2N]) so that
+  // neighbour d + k (mod N) is slot d + k; and the exact-stage request masks
+  float* w[12];                                  // x y z vx vy vz r kd ax ay az prio
+  unsigned long long* mask2;                     // [64] bit jd: run pair_eval(me, jd)
 };
 
-__device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb) {
+__host__ __device__ inline int f32_len(int T, int epb) { return (T + epb + 3) & ~1; }
+
+__device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb, int N) {
   Lds L;
   double* d = reinterpret_cast<double*>(base);
   L.x = d; L.y = d + T; L.z = d + 2 * T; L.vx = d + 3 * T; L.vy = d + 4 * T; L.vz = d + 5 * T;
@@ -277,11 +245,40 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
   L.pk = reinterpret_cast<uint32_t*>(L.iet + (size_t)nm * T);
   L.kept = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
   L.any_reset = L.kept + T;
+  L.far = L.any_reset + epb;
+  const int FL = f32_len(T, epb);
+  // 8-B aligned: everything before is a multiple of 8 bytes when T is even (T is a multiple of 64)
+  L.fx = reinterpret_cast<float*>(L.far + epb + (epb & 1) * 0);
+  if ((reinterpret_cast<uintptr_t>(L.fx) & 7) != 0) L.fx += 1;
+  L.fy = L.fx + FL; L.fz = L.fy + FL; L.fr = L.fz + FL;
   L.T = T;
+  L.Npad = N + (N & 1);
+  // wave-mode arrays alias the generic fp32 region (the two modes never mix)
+  L.mask2 = reinterpret_cast<unsigned long long*>(L.fx);
+  float* wf = reinterpret_cast<float*>(L.mask2 + 64);
+  for (int k = 0; k < 12; ++k) L.w[k] = wf + 128 * k;
   return L;
 }
-__host__ __device__ inline size_t lds_bytes(int T, int nm, int epb) {
-  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 4 + (size_t)epb * 4 + 16;
+__host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, bool wave = false) {
+  const size_t f32 = wave ? (size_t)(64 * 8 + 12 * 128 * 4) : (size_t)f32_len(T, epb) * 16;
+  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 4 + (size_t)epb * 8 + 8 + f32 + 16;
+}
+
+// Stage the fp32 image of one drone and raise the env's `far` flag when a
+// coordinate is outside the bound the bands assume (or is NaN).
+__device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el, int d,
+                                          bool active, const double p[3], double r) {
+  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
+  if (el < P.epb) {
+    const int k = el * L.Npad + d;
+    L.fx[k] = (float)cx; L.fy[k] = (float)cy; L.fz[k] = (float)cz; L.fr[k] = (float)r;
+    if (d == P.N - 1 && (P.N & 1)) {  // pad slot of an odd env: never a candidate
+      L.fx[k + 1] = 3.0e18f; L.fy[k + 1] = 3.0e18f; L.fz[k + 1] = 3.0e18f; L.fr[k + 1] = 0.0f;
+    }
+  }
+  const double cm = (double)P.cmax;
+  if (active && !(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
+    L.far[el] = 1;
 }
 
 __device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
@@ -295,6 +292,148 @@ __device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
 __device__ __forceinline__ double pair_md(const Drone& S, const Drone& O) {
   double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
   return __builtin_sqrt(sq(ry) + sq(rx) + sq(rz)) - O.r;
+}
+
+// Stage X: the exact fp64 evaluation of one candidate pair = the neighbour gate of
+// rvo_inter.preprocess (rvo_inter.py:90-97) followed by rvo_inter.config_vo_circle2
+// (rvo_inter.py:116-196) with get_alpha / get_PAA / vo_out_jud_vector / get_beta
+// (vel_obs3D.py:8-66, rvo_inter.py:212-228).  `a` is the action after the
+// "< 1e-5 -> 0" rule (rvo_inter.py:118).
+__device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, const Lds& L, int k,
+                                             const double a[3]) {
+  PairOut o;
+  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0;
+  const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
+  const double d2 = dot3b(rx, ry, rz, rx, ry, rz);  // np.linalg.norm(dif) ** 2 (sign-symmetric)
+  // gate: norm <= 10 (rvo_inter.py:96) and not the very same position (rvo_inter.py:92)
+  if (!(d2 <= P.T10)) return o;
+  if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) return o;
+  const double Or = L.r[k];
+  const double ssum = sq(ry) + sq(rx) + sq(rz);  // dis ** 2 as rvo_inter.py:135 sums it
+  const double R = S.r + Or;
+  // dis <= thr without the sqrt unless ssum is within 1e-15 (relative) of thr^2
+  const double thr = P.env_train ? R : (S.r - kExpRadius + Or);
+  const double thr2 = thr * thr;
+  bool coll;
+  if (ssum < thr2 * (1.0 - 1e-15)) coll = thr >= 0;
+  else if (ssum > thr2 * (1.0 + 1e-15)) coll = false;
+  else coll = __builtin_sqrt(ssum) <= thr;
+  if (coll) { o.collision = true; return o; }
+  const double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
+  if (dotp <= 0) return o;
+  const double Ovx = L.vx[k], Ovy = L.vy[k], Ovz = L.vz[k], Oprio = L.prio[k];
+  // get_PAA (vel_obs3D.py:19-32); x / (x + x) == 0.5 exactly
+  const double pr = (S.prio == Oprio) ? 0.5 : S.prio / (S.prio + Oprio);
+  const double paax = pr * (2 * S.x + (S.vx + Ovx));
+  const double paay = pr * (2 * S.y + (S.vy + Ovy));
+  const double paaz = pr * (2 * S.z + (S.vz + Ovz));
+  const double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay,
+               wz = (S.z + 2 * a[2]) - paaz;
+  const double dp = dot3b(rx, ry, rz, wx, wy, wz);
+  // dp <= 0: cos <= 0 (or AB == 0 -> cos := 0), beta >= pi/2, beta_c >= 157 >= alpha_c: outside
+  if (dp <= 0) return o;
+  const double w2 = dot3b(wx, wy, wz, wx, wy, wz);
+  // Conservative pre-filter.  Inside needs alpha_c >= beta_c + 1, which implies
+  // beta_raw <= alpha_raw; so cos(beta) < cos(alpha + 1e-4) is surely outside.
+  // |ab| cos(alpha + d) = cos d sqrt(d2 - R^2) - sin d R =: K, cos(beta) = dp / (|ab| |w|).
+  // The square root is taken in fp32 (1e-7 relative); the 1e-5 slack on K^2 covers it.
+  const double K = kCosD * (double)__builtin_sqrtf((float)(d2 - R * R)) - kSinD * R;
+  if (K > 0 && dp * dp < (w2 * (K * K)) * (1.0 - 1e-5)) return o;
+  const double nab = __builtin_sqrt(d2);
+  const double alpha_c = py_round2_c(asin(R / nab));
+  const double AB = nab * __builtin_sqrt(w2);
+  const double cosang = (AB != 0) ? dp / AB : 0.0;
+  const double beta_c = __builtin_rint(acos(cosang) * 100.0);  // NaN when |cos| > 1 (np.arccos)
+  if (!(alpha_c > beta_c)) return o;  // alpha > beta on the rounded values (rvo_inter.py:226)
+  const double rvx = 2 * a[0] - Ovx - S.vx, rvy = 2 * a[1] - Ovy - S.vy,
+               rvz = 2 * a[2] - Ovz - S.vz;
+  const double t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, Or);
+  if (t < kCtimeThreshold) {
+    o.flag = true;
+    o.t = t;
+    o.iet = 1 / (t + 0.2);
+    o.md = __builtin_sqrt(ssum) - Or;
+    o.alpha_c = (int)alpha_c;
+  }
+  return o;
+}
+
+// Insert one flagged pair into the kept VO rows of lane `tid` (LDS), keeping the nm
+// most urgent in the order of list.sort(reverse=True, key=(-iet, min_dis)) (stable):
+// ascending iet, then descending min_dis, then ascending j; slot 0 = least urgent
+// kept.  The order is total, so the result does not depend on insertion order.
+__device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int tid, int lbase,
+                                          const Drone& S, const PairOut& po, int j, int kept) {
+  const int T = L.T;
+  // position among kept rows: first slot whose row is more urgent than the new one
+  int pos = kept;
+  for (int s = 0; s < kept; ++s) {
+    const double ie = L.iet[s * T + tid];
+    bool new_first;  // new row sorts before slot s
+    if (po.iet != ie) new_first = po.iet < ie;
+    else {
+      const int js = (int)(L.pk[s * T + tid] & 0xffffu);
+      const double mds = pair_md(S, lds_drone(L, lbase + js));
+      new_first = (po.md != mds) ? (po.md > mds) : (j < js);
+    }
+    if (new_first) { pos = s; break; }
+  }
+  const uint32_t packed = ((uint32_t)po.alpha_c << 16) | (uint32_t)j;
+  if (kept < P.nm) {  // grow: shift [pos, kept) up by one
+    for (int s = kept; s > pos; --s) {
+      L.iet[s * T + tid] = L.iet[(s - 1) * T + tid];
+      L.pk[s * T + tid] = L.pk[(s - 1) * T + tid];
+    }
+    L.iet[pos * T + tid] = po.iet;
+    L.pk[pos * T + tid] = packed;
+    ++kept;
+  } else if (pos > 0) {  // full: drop slot 0 (least urgent), insert at pos-1
+    for (int s = 0; s < pos - 1; ++s) {
+      L.iet[s * T + tid] = L.iet[(s + 1) * T + tid];
+      L.pk[s * T + tid] = L.pk[(s + 1) * T + tid];
+    }
+    L.iet[(pos - 1) * T + tid] = po.iet;
+    L.pk[(pos - 1) * T + tid] = packed;
+  }
+  return kept;
+}
+
+// Stage G for up to 32 consecutive neighbours starting at fp32 slot `fb`:
+// bit jj is set when neighbour fb + jj is possibly in range and possibly
+// approaching (ROWS: or possibly touching).  Pure filter: stage X repeats
+// every test exactly.  Reads slot pairs (the slot behind an odd env is a pad).
+template <bool ROWS>
+__device__ __forceinline__ uint32_t gate32(const Params& P, const Lds& L, int fb, int cnt,
+                                           float mex, float mey, float mez, float mer, float fvx,
+                                           float fvy, float fvz, float kd) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez};
+  const v2f svx = {fvx, fvx}, svy = {fvy, fvy}, svz = {fvz, fvz};
+  uint32_t m = 0u;
+  for (int jj = 0; jj < cnt; jj += 2) {
+    const v2f dx = *reinterpret_cast<const v2f*>(L.fx + fb + jj) - sx;
+    const v2f dy = *reinterpret_cast<const v2f*>(L.fy + fb + jj) - sy;
+    const v2f dz = *reinterpret_cast<const v2f*>(L.fz + fb + jj) - sz;
+    v2f d2 = dx * dx;
+    d2 = __builtin_elementwise_fma(dy, dy, d2);
+    d2 = __builtin_elementwise_fma(dz, dz, d2);
+    v2f dt = svx * dx;
+    dt = __builtin_elementwise_fma(svy, dy, dt);
+    dt = __builtin_elementwise_fma(svz, dz, dt);
+    bool b0 = (d2.x <= P.t10f) && (dt.x > -kd);
+    bool b1 = (d2.y <= P.t10f) && (dt.y > -kd);
+    if (ROWS) {  // collisions count whatever the direction of motion
+      const v2f rs = *reinterpret_cast<const v2f*>(L.fr + fb + jj) + (v2f){mer, mer};
+      const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
+                                               (v2f){P.band, P.band});
+      b0 = b0 || (d2.x <= rc.x);
+      b1 = b1 || (d2.y <= rc.y);
+    }
+    m |= (b0 ? 1u : 0u) << jj;
+    m |= (b1 ? 2u : 0u) << jj;
+  }
+  if (cnt < 32) m &= (1u << cnt) - 1u;  // odd tail: the pad / next env's slot
+  return m;
 }
 
 // Sweep over the other drones of my env (rvo_inter.preprocess gate,
@@ -312,60 +451,193 @@ __device__ __forceinline__ int sweep(const Params& P, const Lds& L, int tid, int
   tmin = __builtin_inf();
   int kept = 0;
   const int N = P.N, T = L.T;
+  // per-lane constants of the fp32 filter
+  const int el = lbase / N, me_j = tid - lbase;
+  const int fbase = el * L.Npad;
+  const float mex = L.fx[fbase + me_j], mey = L.fy[fbase + me_j], mez = L.fz[fbase + me_j],
+              mer = L.fr[fbase + me_j];
+  const float fvx = (float)S.vx, fvy = (float)S.vy, fvz = (float)S.vz;
+  // v.rel > -kd is "possibly approaching"
+  const float kd = P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f;
+  const bool far = L.far[el] != 0;
   for (int c0 = 0; c0 < N; c0 += 64) {
     const int cn = (N - c0) < 64 ? (N - c0) : 64;
-    unsigned long long mask = 0ull;
-    for (int jj = 0; jj < cn; ++jj) {  // gate: full lane utilisation, no sqrt
-      const int k = lbase + c0 + jj;
-      const double dx = S.x - L.x[k], dy = S.y - L.y[k], dz = S.z - L.z[k];
-      const double d2 = dot3b(dx, dy, dz, dx, dy, dz);
-      // norm <= 10 (rvo_inter.py:96) and not the same position (rvo_inter.py:92):
-      // d2 == 0 with a non-zero difference needs |dif| < 1e-154, handled exactly anyway
-      const bool in = (d2 <= P.T10) && (d2 > 0.0 || dx != 0.0 || dy != 0.0 || dz != 0.0);
-      if (in) mask |= (1ull << jj);
+    uint32_t mlo, mhi;
+    if (far) {  // a coordinate is outside the filter's bound: every neighbour is a candidate
+      const unsigned long long all = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
+      mlo = (uint32_t)all; mhi = (uint32_t)(all >> 32);
+    } else {  // stage G: two neighbours per packed instruction
+      mlo = gate32<ROWS>(P, L, fbase + c0, cn < 32 ? cn : 32, mex, mey, mez, mer, fvx, fvy, fvz, kd);
+      mhi = cn > 32 ? gate32<ROWS>(P, L, fbase + c0 + 32, cn - 32, mex, mey, mez, mer, fvx, fvy,
+                                   fvz, kd)
+                    : 0u;
     }
-    while (mask) {  // only in-range neighbours
+    unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
+    if (me_j >= c0 && me_j < c0 + 64) mask &= ~(1ull << (me_j - c0));  // j != i (ir_gym.py:56)
+    while (mask) {  // stage X: exact, candidates only
       const int jj = __builtin_ctzll(mask);
       mask &= mask - 1;
       const int j = c0 + jj;
-      const Drone O = lds_drone(L, lbase + j);
-      const PairOut po = pair_eval(S, O, a, P.env_train);
+      const PairOut po = pair_eval(P, S, L, lbase + j, a);
       if (ROWS && po.collision) collision = true;
       if (po.flag) {
         flag = true;
         if (po.t < tmin) tmin = po.t;
         if (ROWS && P.nm > 0) {
-          // position among kept rows: first slot whose row is more urgent than the new one
-          int pos = kept;
-          for (int s = 0; s < kept; ++s) {
-            const double ie = L.iet[s * T + tid];
-            bool new_first;  // new row sorts before slot s
-            if (po.iet != ie) new_first = po.iet < ie;
-            else {
-              const int js = (int)(L.pk[s * T + tid] & 0xffffu);
-              const double mds = pair_md(S, lds_drone(L, lbase + js));
-              new_first = (po.md != mds) ? (po.md > mds) : (j < js);
+          kept = insert_row(P, L, tid, lbase, S, po, j, kept);
+        }
+      }
+    }
+  }
+  return kept;
+}
+
+// ===== wave mode (N <= 64: whole envs inside one wave, workgroup = one wave) =====
+enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
+
+// fp32 image of one drone, written to both copies of its env segment.
+__device__ __forceinline__ void stage_wave(const Params& P, const Lds& L, int el, int d,
+                                           bool active, const double p[3], const double v[3],
+                                           const double az[3], double r, double prio) {
+  if (!active) return;
+  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
+  const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
+  const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
+                         P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
+                         (float)az[0], (float)az[1], (float)az[2], (float)prio};
+  const int o = el * 2 * P.N + d;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
+  const double cm = (double)P.cmax;
+  if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
+    L.far[el] = 1;
+}
+
+// Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
+// lane whose drone index d satisfies j = d + k (mod N), 1 <= k <= N/2.
+//   stage G  (packed fp32, all offsets): possibly in range and (possibly approaching
+//            in either direction, or possibly touching);
+//   stage X1 (fp32, candidates): conservative cone pre-filter for both directions;
+//            survivors request the exact evaluation from the owner (own register /
+//            LDS bit mask of the neighbour);
+//   stage X2 (fp64, requested pairs only): pair_eval, exactly as the generic path.
+// G and X1 only ever drop pairs that pair_eval would return "nothing" for.
+template <bool ROWS>
+__device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lane, int el, int d,
+                                          bool active, const Drone& S, const double a[3],
+                                          bool zero_act, bool& flag, double& tmin,
+                                          bool& collision) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  flag = false;
+  tmin = __builtin_inf();
+  int kept = 0;
+  const int N = P.N, H = N >> 1, T = L.T;
+  L.mask2[lane] = 0ull;
+  __syncthreads();
+  unsigned long long m2 = 0ull;
+  if (active) {
+    const int o0 = el * 2 * N + d;
+    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
+    const float mvx = L.w[WVX][o0], mvy = L.w[WVY][o0], mvz = L.w[WVZ][o0];
+    const float mer = L.w[WR][o0], mkd = L.w[WKD][o0], mprio = L.w[WPRIO][o0];
+    const float max_ = zero_act ? 0.f : L.w[WAX][o0], may = zero_act ? 0.f : L.w[WAY][o0],
+                maz = zero_act ? 0.f : L.w[WAZ][o0];
+    const bool far = L.far[el] != 0;
+    uint32_t valid = H >= 32 ? 0xffffffffu : ((1u << H) - 1u);
+    if (!(N & 1) && d >= H && H > 0) valid &= ~(1u << (H - 1));  // offset N/2 belongs to d < N/2
+    uint32_t cand = 0u;
+    if (far) {
+      cand = valid;
+    } else {
+      const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez};
+      const v2f svx = {mvx, mvx}, svy = {mvy, mvy}, svz = {mvz, mvz};
+      for (int k = 1; k <= H; k += 2) {  // stage G: offsets k and k + 1
+        const int o = o0 + k;
+        const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
+        const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
+        const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
+        v2f d2 = dx * dx;
+        d2 = __builtin_elementwise_fma(dy, dy, d2);
+        d2 = __builtin_elementwise_fma(dz, dz, d2);
+        v2f di = svx * dx;  // v_i . rel
+        di = __builtin_elementwise_fma(svy, dy, di);
+        di = __builtin_elementwise_fma(svz, dz, di);
+        v2f dj = (v2f){L.w[WVX][o], L.w[WVX][o + 1]} * dx;  // v_j . rel
+        dj = __builtin_elementwise_fma((v2f){L.w[WVY][o], L.w[WVY][o + 1]}, dy, dj);
+        dj = __builtin_elementwise_fma((v2f){L.w[WVZ][o], L.w[WVZ][o + 1]}, dz, dj);
+        const float kj0 = L.w[WKD][o], kj1 = L.w[WKD][o + 1];
+        bool b0 = (d2.x <= P.t10f) && ((di.x > -mkd) || (dj.x < kj0));
+        bool b1 = (d2.y <= P.t10f) && ((di.y > -mkd) || (dj.y < kj1));
+        if (ROWS) {  // possibly touching: collisions count whatever the motion
+          const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + (v2f){mer, mer};
+          const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
+                                                   (v2f){P.band, P.band});
+          b0 = b0 || (d2.x <= rc.x);
+          b1 = b1 || (d2.y <= rc.y);
+        }
+        cand |= (b0 ? 1u : 0u) << (k - 1);
+        cand |= (b1 ? 2u : 0u) << (k - 1);
+      }
+      cand &= valid;
+    }
+    while (cand) {  // stage X1: both directions of one candidate pair
+      const int kb = __builtin_ctz(cand);
+      cand &= cand - 1;
+      const int o = o0 + kb + 1;
+      int jd = d + kb + 1;
+      if (jd >= N) jd -= N;
+      bool pi = true, pj = true;
+      if (!far) {
+        const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float rs = L.w[WR][o] + mer;
+        const bool touch = ROWS && (d2 <= __builtin_fmaf(rs * rs, 1.00001f, P.band));
+        if (!touch) {
+          const float jvx = L.w[WVX][o], jvy = L.w[WVY][o], jvz = L.w[WVZ][o];
+          pi = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
+          pj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < L.w[WKD][o];
+          const float gap = d2 - rs * rs;  // d^2 - R^2
+          if (gap >= P.x1_gap && L.w[WPRIO][o] == mprio) {
+            // |ab| cos(alpha + 2e-3) (fp32, slack x1_k2 on its square)
+            const float K = 0.999998f * __builtin_sqrtf(gap) - 2.0e-3f * rs;
+            const float K2 = K * K * P.x1_k2;
+            const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
+            if (pi) {  // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
+              const float wx = 2.f * max_ - hx, wy = 2.f * may - hy, wz = 2.f * maz - hz;
+              const float dp = __builtin_fmaf(dz, wz, __builtin_fmaf(dy, wy, dx * wx));
+              const float w2 = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
+              const float dp2 = dp * dp;
+              if (dp < 0.f ? (dp2 > P.x1_cs2 * d2 * w2) : (K > 0.f && dp2 < w2 * K2)) pi = false;
             }
-            if (new_first) { pos = s; break; }
-          }
-          const uint32_t packed = ((uint32_t)po.alpha_c << 16) | (uint32_t)j;
-          if (kept < P.nm) {  // grow: shift [pos, kept) up by one
-            for (int s = kept; s > pos; --s) {
-              L.iet[s * T + tid] = L.iet[(s - 1) * T + tid];
-              L.pk[s * T + tid] = L.pk[(s - 1) * T + tid];
+            if (pj) {  // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
+              const float ajx = zero_act ? 0.f : L.w[WAX][o], ajy = zero_act ? 0.f : L.w[WAY][o],
+                          ajz = zero_act ? 0.f : L.w[WAZ][o];
+              const float wx = 2.f * ajx - hx, wy = 2.f * ajy - hy, wz = 2.f * ajz - hz;
+              const float dp = -__builtin_fmaf(dz, wz, __builtin_fmaf(dy, wy, dx * wx));
+              const float w2 = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
+              const float dp2 = dp * dp;
+              if (dp < 0.f ? (dp2 > P.x1_cs2 * d2 * w2) : (K > 0.f && dp2 < w2 * K2)) pj = false;
             }
-            L.iet[pos * T + tid] = po.iet;
-            L.pk[pos * T + tid] = packed;
-            ++kept;
-          } else if (pos > 0) {  // full: drop slot 0 (least urgent), insert at pos-1
-            for (int s = 0; s < pos - 1; ++s) {
-              L.iet[s * T + tid] = L.iet[(s + 1) * T + tid];
-              L.pk[s * T + tid] = L.pk[(s + 1) * T + tid];
-            }
-            L.iet[(pos - 1) * T + tid] = po.iet;
-            L.pk[(pos - 1) * T + tid] = packed;
           }
         }
+      }
+      if (pi) m2 |= 1ull << jd;
+      if (pj) atomicOr(&L.mask2[el * N + jd], 1ull << d);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    m2 |= L.mask2[lane];
+    const int lbase = el * N;
+    while (m2) {  // stage X2: exact, requested pairs only
+      const int j = __builtin_ctzll(m2);
+      m2 &= m2 - 1;
+      const PairOut po = pair_eval(P, S, L, lbase + j, a);
+      if (ROWS && po.collision) collision = true;
+      if (po.flag) {
+        flag = true;
+        if (po.t < tmin) tmin = po.t;
+        if (ROWS && P.nm > 0) kept = insert_row(P, L, lane, lbase, S, po, j, kept);
       }
     }
   }
@@ -538,12 +810,30 @@ __device__ __forceinline__ float reward_f32(double k1, double k2) {
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
+#ifndef RVO3D_WAVES_ATTR
+#define RVO3D_WAVES_ATTR
+#endif
+
+// One sweep of my env, by whichever pipeline the launch uses.  Called by every
+// thread of the workgroup (the wave pipeline synchronises inside).
+template <bool WAVE, bool ROWS>
+__device__ __forceinline__ int do_sweep(const Params& P, const Lds& L, int tid, int el, int d,
+                                        bool act, const Drone& S, const double a[3],
+                                        bool zero_act, bool& flag, double& tmin,
+                                        bool& collision) {
+  if (WAVE) return sweep_wave<ROWS>(P, L, tid, el, d, act, S, a, zero_act, flag, tmin, collision);
+  flag = false;
+  tmin = __builtin_inf();
+  return act ? sweep<ROWS>(P, L, tid, el * P.N, S, a, flag, tmin, collision) : 0;
+}
+
 // The whole environment step, one launch.
-template <int MODE>
-__global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
+template <int MODE, bool WAVE>
+__global__ void __launch_bounds__(WAVE ? 64 : kMaxThreads) RVO3D_WAVES_ATTR
+env_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, T = blockDim.x, N = P.N;
-  const Lds L = carve_lds(smem, T, P.nm, P.epb);
+  const Lds L = carve_lds(smem, T, P.nm, P.epb, N);
   const int el = tid / N;
   const int d = tid - el * N;
   const int e0 = blockIdx.x * P.epb;
@@ -593,21 +883,28 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
   }
-  if (tid < P.epb) L.any_reset[tid] = 0;
+  double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
+  if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
+  const double zero3[3] = {0, 0, 0};
+
+  if (tid < P.epb) { L.any_reset[tid] = 0; L.far[tid] = 0; }
   L.kept[tid] = 0;
+  __syncthreads();  // flags zeroed before anyone raises them
   L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
   L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
   L.r[tid] = S.r; L.prio[tid] = S.prio;
+  if (WAVE) stage_wave(P, L, el, d, active, p, v, az, S.r, S.prio);
+  else stage_f32(P, L, el, d, active, p, S.r);
   __syncthreads();
   S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
   bool flag, collision = false;
   double tmin;
-  const double zero3[3] = {0, 0, 0};
 
   if (MODE == kObserve) {
+    const int kept = do_sweep<WAVE, true>(P, L, tid, el, d, active, S, zero3, true, flag, tmin,
+                                          collision);
     if (active) {
-      const int kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, collision);
       write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
       L.kept[tid] = kept;
       P.max_dev[g] = max_dev;
@@ -618,13 +915,10 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
   }
 
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
-  double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
-  if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
   double rew_k = 0;
-  if (active) {
-    sweep<false>(P, L, tid, lbase, S, az, flag, tmin, collision);
-    rew_k = rvo_reward_k(dv, a, flag, tmin);
-  }
+  do_sweep<WAVE, false>(P, L, tid, el, d, active && !(P.ablate & 1), S, az, false, flag, tmin,
+                        collision);
+  if (active) rew_k = rvo_reward_k(dv, a, flag, tmin);
   __syncthreads();  // everyone is done with the pre-move LDS image
 
   // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490)
@@ -665,15 +959,16 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
   }
   L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
   L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
+  if (WAVE) stage_wave(P, L, el, d, active, p, v, az, S.r, S.prio);
+  else stage_f32(P, L, el, d, active, p, S.r);
   __syncthreads();
   S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
   // ---- sweep B: ir_gym.observation_reward on the post-move state (ir_gym.py:156-254)
-  bool do_reset = false;
-  int kept = 0;
+  bool do_reset = false, arrive_r = false, dest_r = false;
+  const int waypoint_num = wpi;
+  double exlen = 0;
   if (active) {
-    bool arrive_r = false, dest_r = false;
-    const int waypoint_num = wpi;
     if (!f_arrive && arrived(P, p, cur)) { f_arrive = true; arrive_r = true; }
     if (f_arrive) {
       if (arrived(P, p, dst)) {
@@ -681,15 +976,17 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
         if (!f_dest) { f_dest = true; dest_r = true; }
       }
     }
-    const double exlen = real_len - route_len + 4;
-    const bool len_flag = exlen > 0;
+    exlen = real_len - route_len + 4;
     collision = building_hit(P, S);
-    kept = sweep<true>(P, L, tid, lbase, S, az, flag, tmin, collision);
+  }
+  int kept = do_sweep<WAVE, true>(P, L, tid, el, d, active && !(P.ablate & 2), S, az, false, flag,
+                                  tmin, collision);
+  if (active) {
     if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
         p[2] > P.map[2])
       collision = true;  // drone.drone_out_map, drone.py:213-225
     const double mr_k = mov_reward_k(P, collision, arrive_r, waypoint_num, npts - 1, dest_r,
-                                     dev, len_flag, exlen);
+                                     dev, exlen > 0, exlen);
     P.reward[g] = reward_f32(rew_k, mr_k);  // mdin.py:28
     P.done[g] = collision ? 1 : 0;
     P.info[g] = f_arrive ? 1 : 0;
@@ -703,7 +1000,7 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     __syncthreads();  // sweep B reads done; any_reset visible
     const bool env_reset = active && (L.any_reset[el] != 0);
     if (active && !env_reset) {  // this env keeps the step's observation: write it now
-      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+      if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
       L.kept[tid] = kept;
     }
     if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
@@ -718,14 +1015,18 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
       if (dev > max_dev) max_dev = dev;
       L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
       L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
+      if (WAVE) stage_wave(P, L, el, d, true, p, v, az, S.r, S.prio);
+      else stage_f32(P, L, el, d, true, p, S.r);
     }
     __syncthreads();
-    if (env_reset) {  // ir_gym.env_observation for the whole env (ir_gym.py:372-383)
-      S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
-      bool c2 = false;
-      kept = sweep<true>(P, L, tid, lbase, S, zero3, flag, tmin, c2);
-      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
-      L.kept[tid] = kept;
+    // ir_gym.env_observation for every env that reset a drone (ir_gym.py:372-383)
+    S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
+    bool c2 = false;
+    const int kept_c = do_sweep<WAVE, true>(P, L, tid, el, d, env_reset && !(P.ablate & 4), S,
+                                            zero3, true, flag, tmin, c2);
+    if (env_reset) {
+      if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept_c);
+      L.kept[tid] = kept_c;
     }
   } else if (active) {
     write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
@@ -741,7 +1042,7 @@ __global__ void __launch_bounds__(kMaxThreads) env_kernel(const Params P) {
     P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
   }
   __syncthreads();  // L.kept complete
-  zero_fill(P, L, tid, e0 * N, nrows);
+  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
 }
 
 // ---- small state kernels -------------------------------------------------------
