@@ -206,6 +206,11 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     }
     P.zf_magic = m;
   }
+  P.zf_q = 0; P.zf_m40 = 0;
+  if ((P.W & 1) == 0) {
+    P.zf_q = (uint32_t)(P.W / 2);  // row bytes / 8
+    P.zf_m40 = ((1ull << 40) + P.zf_q - 1) / P.zf_q;
+  }
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;
@@ -325,6 +330,7 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   if (!obs || !vo_count) return fail(RVO3D_ERR_INVALID, "obs / vo_count are required");
   Params P = h->P;
   P.obs = obs; P.vo_count = vo_count;
+  P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   return launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
 }
 
@@ -340,6 +346,7 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   Params P = h->P;
   P.actions = actions; P.action_f64 = action_dtype == RVO3D_F64;
   P.obs = obs; P.vo_count = vo_count; P.reward = reward;
+  P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);

@@ -48,6 +48,9 @@ struct Params {
   int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
+  uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
+  unsigned long long zf_m40;  // ceil(2^40 / zf_q)
+  int zf16;           // per call: obs is 16-B aligned and W is even -> 16-B zero-fill
   double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
   double map[3];
   double T10, T5, T04;  // max{x : sqrt(x) <= 10 | 5 | 0.4}  (rvo_inter.py:96,104; drone.py:15)
@@ -224,6 +227,7 @@ struct Lds {
   double* iet;                                   // [nm][T] kept VO rows, ascending urgency
   uint32_t* pk;                                  // [nm][T] (alpha_c << 16) | j
   int* kept;                                     // [T] rows kept by the final sweep
+  uint32_t* zc;                                  // [2T] per row: first / end 16-B chunk of its zero run
   int* any_reset;                                // [epb]
   int* far;                                      // [epb] a drone is outside the fp32 filter's bound
   float *fx, *fy, *fz, *fr;                      // [epb * Npad] centred x, y, z, radius in fp32
@@ -244,7 +248,8 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
   L.iet = d + 8 * T;
   L.pk = reinterpret_cast<uint32_t*>(L.iet + (size_t)nm * T);
   L.kept = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
-  L.any_reset = L.kept + T;
+  L.zc = reinterpret_cast<uint32_t*>(L.kept + T);
+  L.any_reset = reinterpret_cast<int*>(L.zc + 2 * T);
   L.far = L.any_reset + epb;
   const int FL = f32_len(T, epb);
   // 8-B aligned: everything before is a multiple of 8 bytes when T is even (T is a multiple of 64)
@@ -261,7 +266,7 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
 }
 __host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, bool wave = false) {
   const size_t f32 = wave ? (size_t)(64 * 8 + 12 * 128 * 4) : (size_t)f32_len(T, epb) * 16;
-  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 4 + (size_t)epb * 8 + 8 + f32 + 16;
+  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 12 + (size_t)epb * 8 + 8 + f32 + 16;
 }
 
 // Stage the fp32 image of one drone and raise the env's `far` flag when a
@@ -550,7 +555,7 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
       cand = valid;
     } else {
       const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez};
-      const v2f svx = {mvx, mvx}, svy = {mvy, mvy}, svz = {mvz, mvz};
+#pragma unroll 2
       for (int k = 1; k <= H; k += 2) {  // stage G: offsets k and k + 1
         const int o = o0 + k;
         const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
@@ -559,74 +564,62 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
         v2f d2 = dx * dx;
         d2 = __builtin_elementwise_fma(dy, dy, d2);
         d2 = __builtin_elementwise_fma(dz, dz, d2);
-        v2f di = svx * dx;  // v_i . rel
-        di = __builtin_elementwise_fma(svy, dy, di);
-        di = __builtin_elementwise_fma(svz, dz, di);
-        v2f dj = (v2f){L.w[WVX][o], L.w[WVX][o + 1]} * dx;  // v_j . rel
-        dj = __builtin_elementwise_fma((v2f){L.w[WVY][o], L.w[WVY][o + 1]}, dy, dj);
-        dj = __builtin_elementwise_fma((v2f){L.w[WVZ][o], L.w[WVZ][o + 1]}, dz, dj);
-        const float kj0 = L.w[WKD][o], kj1 = L.w[WKD][o + 1];
-        bool b0 = (d2.x <= P.t10f) && ((di.x > -mkd) || (dj.x < kj0));
-        bool b1 = (d2.y <= P.t10f) && ((di.y > -mkd) || (dj.y < kj1));
-        if (ROWS) {  // possibly touching: collisions count whatever the motion
-          const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + (v2f){mer, mer};
-          const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
-                                                   (v2f){P.band, P.band});
-          b0 = b0 || (d2.x <= rc.x);
-          b1 = b1 || (d2.y <= rc.y);
-        }
-        cand |= (b0 ? 1u : 0u) << (k - 1);
-        cand |= (b1 ? 2u : 0u) << (k - 1);
+        // possibly in range (covers "possibly touching" as long as R^2 + band <= t10f)
+        const uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
+        cand |= (b0 | (b1 << 1)) << (k - 1);
       }
       cand &= valid;
     }
+    if (P.ablate & 64) cand = 0;
     while (cand) {  // stage X1: both directions of one candidate pair
       const int kb = __builtin_ctz(cand);
       cand &= cand - 1;
       const int o = o0 + kb + 1;
       int jd = d + kb + 1;
       if (jd >= N) jd -= N;
-      bool pi = true, pj = true;
-      if (!far) {
-        const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float rs = L.w[WR][o] + mer;
-        const bool touch = ROWS && (d2 <= __builtin_fmaf(rs * rs, 1.00001f, P.band));
-        if (!touch) {
-          const float jvx = L.w[WVX][o], jvy = L.w[WVY][o], jvz = L.w[WVZ][o];
-          pi = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
-          pj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < L.w[WKD][o];
-          const float gap = d2 - rs * rs;  // d^2 - R^2
-          if (gap >= P.x1_gap && L.w[WPRIO][o] == mprio) {
-            // |ab| cos(alpha + 2e-3) (fp32, slack x1_k2 on its square)
-            const float K = 0.999998f * __builtin_sqrtf(gap) - 2.0e-3f * rs;
-            const float K2 = K * K * P.x1_k2;
-            const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
-            if (pi) {  // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
-              const float wx = 2.f * max_ - hx, wy = 2.f * may - hy, wz = 2.f * maz - hz;
-              const float dp = __builtin_fmaf(dz, wz, __builtin_fmaf(dy, wy, dx * wx));
-              const float w2 = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
-              const float dp2 = dp * dp;
-              if (dp < 0.f ? (dp2 > P.x1_cs2 * d2 * w2) : (K > 0.f && dp2 < w2 * K2)) pi = false;
-            }
-            if (pj) {  // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
-              const float ajx = zero_act ? 0.f : L.w[WAX][o], ajy = zero_act ? 0.f : L.w[WAY][o],
-                          ajz = zero_act ? 0.f : L.w[WAZ][o];
-              const float wx = 2.f * ajx - hx, wy = 2.f * ajy - hy, wz = 2.f * ajz - hz;
-              const float dp = -__builtin_fmaf(dz, wz, __builtin_fmaf(dy, wy, dx * wx));
-              const float w2 = __builtin_fmaf(wz, wz, __builtin_fmaf(wy, wy, wx * wx));
-              const float dp2 = dp * dp;
-              if (dp < 0.f ? (dp2 > P.x1_cs2 * d2 * w2) : (K > 0.f && dp2 < w2 * K2)) pj = false;
-            }
-          }
-        }
-      }
+      // straight-line fp32; booleans are combined bitwise on purpose (no branches)
+      const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
+      const float jvx = L.w[WVX][o], jvy = L.w[WVY][o], jvz = L.w[WVZ][o];
+      const float jr = L.w[WR][o], jkd = L.w[WKD][o], jprio = L.w[WPRIO][o];
+      const float ajx = zero_act ? 0.f : L.w[WAX][o], ajy = zero_act ? 0.f : L.w[WAY][o],
+                  ajz = zero_act ? 0.f : L.w[WAZ][o];
+      const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      const float rs = jr + mer;
+      const float rs2 = rs * rs;
+      const int touch = ROWS & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
+      // possibly approaching, each direction (v.rel > -eps)
+      const int ai = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
+      const int aj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < jkd;
+      // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
+      const float gap = d2 - rs2;  // d^2 - R^2
+      const int filt = (int)(gap >= P.x1_gap) & (int)(jprio == mprio);
+      const float K = 0.999998f * __builtin_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
+      const float K2 = K * K * P.x1_k2;
+      const int kpos = K > 0.f;
+      const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
+      // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
+      const float wix = 2.f * max_ - hx, wiy = 2.f * may - hy, wiz = 2.f * maz - hz;
+      const float dpi = __builtin_fmaf(dz, wiz, __builtin_fmaf(dy, wiy, dx * wix));
+      const float wi2 = __builtin_fmaf(wiz, wiz, __builtin_fmaf(wiy, wiy, wix * wix));
+      // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
+      const float wjx = 2.f * ajx - hx, wjy = 2.f * ajy - hy, wjz = 2.f * ajz - hz;
+      const float dpj = -__builtin_fmaf(dz, wjz, __builtin_fmaf(dy, wjy, dx * wjx));
+      const float wj2 = __builtin_fmaf(wjz, wjz, __builtin_fmaf(wjy, wjy, wjx * wjx));
+      const float cs = P.x1_cs2 * d2;
+      // surely outside: cos < -cs, or 0 <= cos < cos(alpha + delta) with slack
+      const int oi = ((int)(dpi < 0.f) & (int)(dpi * dpi > cs * wi2)) |
+                     ((int)(dpi >= 0.f) & kpos & (int)(dpi * dpi < wi2 * K2));
+      const int oj = ((int)(dpj < 0.f) & (int)(dpj * dpj > cs * wj2)) |
+                     ((int)(dpj >= 0.f) & kpos & (int)(dpj * dpj < wj2 * K2));
+      const int fr = far ? 1 : 0;
+      const bool pi = (fr | touch | (ai & ~(filt & oi))) & 1;
+      const bool pj = (fr | touch | (aj & ~(filt & oj))) & 1;
       if (pi) m2 |= 1ull << jd;
       if (pj) atomicOr(&L.mask2[el * N + jd], 1ull << d);
     }
   }
   __syncthreads();
-  if (active) {
+  if (active && !(P.ablate & 32)) {
     m2 |= L.mask2[lane];
     const int lbase = el * N;
     while (m2) {  // stage X2: exact, requested pairs only
@@ -706,6 +699,20 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
   }
   // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
   if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
+  if (P.zf16) {
+    // 16-B zero-fill: this lane writes the 8-B pieces that do not fill a 16-B chunk at
+    // either end of its zero run and publishes the run as a chunk range [c0, c1)
+    const unsigned long long rb = 4ull * (unsigned)P.W;
+    const unsigned long long row_b = rb * (unsigned long long)g;
+    unsigned long long zs = row_b + 4ull * (unsigned)((12 + 9 * kept + 1) & ~1);
+    unsigned long long ze = row_b + rb;
+    char* ob = reinterpret_cast<char*>(P.obs);
+    if (zs < ze && (zs & 8)) { *reinterpret_cast<float2*>(ob + zs) = make_float2(0.f, 0.f); zs += 8; }
+    if (zs < ze && (ze & 8)) { ze -= 8; *reinterpret_cast<float2*>(ob + ze) = make_float2(0.f, 0.f); }
+    if (zs > ze) zs = ze;
+    L.zc[2 * tid] = (uint32_t)(zs >> 4);
+    L.zc[2 * tid + 1] = (uint32_t)(ze >> 4);
+  }
   P.vo_count[g] = kept;
   if (bad) atomicOr(P.err, 1u);
 }
@@ -716,6 +723,20 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
 // float otherwise.
 __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid, int row0,
                                           int nrows) {
+  if (P.zf16) {
+    // rows [row0, row0 + nrows) occupy bytes [rb*row0, rb*(row0+nrows)); every 16-B chunk
+    // that starts inside a row's published zero run is stored, fully coalesced
+    const unsigned long long rb = 4ull * (unsigned)P.W;
+    const uint32_t cbeg = (uint32_t)((rb * (unsigned)row0 + 15) >> 4);
+    const uint32_t cend = (uint32_t)((rb * (unsigned)(row0 + nrows)) >> 4);
+    float4* ob = reinterpret_cast<float4*>(P.obs);
+    for (uint32_t c = cbeg + tid; c < cend; c += L.T) {
+      const uint32_t grow = (uint32_t)(((unsigned long long)(2u * c) * P.zf_m40) >> 40);
+      const uint32_t lr = grow - (uint32_t)row0;
+      if (c >= L.zc[2 * lr] && c < L.zc[2 * lr + 1]) ob[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return;
+  }
   const uint32_t per_row = P.zf_div;
   if (per_row == 0) return;
   const uint32_t total = (uint32_t)nrows * per_row;
