@@ -527,7 +527,7 @@ __device__ __forceinline__ void stage_wave(const Params& P, const Lds& L, int el
 //            LDS bit mask of the neighbour);
 //   stage X2 (fp64, requested pairs only): pair_eval, exactly as the generic path.
 // G and X1 only ever drop pairs that pair_eval would return "nothing" for.
-template <bool ROWS>
+template <bool ROWS, bool TOUCH>
 __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lane, int el, int d,
                                           bool active, const Drone& S, const double a[3],
                                           bool zero_act, bool& flag, double& tmin,
@@ -586,7 +586,7 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
       const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
       const float rs = jr + mer;
       const float rs2 = rs * rs;
-      const int touch = ROWS & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
+      const int touch = TOUCH & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
       // possibly approaching, each direction (v.rel > -eps)
       const int ai = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
       const int aj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < jkd;
@@ -626,7 +626,7 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
       const int j = __builtin_ctzll(m2);
       m2 &= m2 - 1;
       const PairOut po = pair_eval(P, S, L, lbase + j, a);
-      if (ROWS && po.collision) collision = true;
+      if (TOUCH && po.collision) collision = true;
       if (po.flag) {
         flag = true;
         if (po.t < tmin) tmin = po.t;
@@ -635,6 +635,73 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
     }
   }
   return kept;
+}
+
+// Collision-only sweep (wave mode): exactly the collision_flag part of
+// rvo_inter.config_vo_inf (rvo_inter.py:40-48) - a neighbour inside the 10 m gate,
+// not at the very same position, with dis <= r + mr (env_train) - for every drone
+// of the env.  Each unordered pair is tested once; the fp32 stage only selects
+// pairs that are possibly touching, the decision itself is fp64.
+__device__ __forceinline__ bool collide_wave(const Params& P, const Lds& L, int lane, int el,
+                                             int d, bool active, const Drone& S) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const int N = P.N, H = N >> 1;
+  L.mask2[lane] = 0ull;
+  __syncthreads();
+  bool coll = false;
+  if (active) {
+    const int o0 = el * 2 * N + d;
+    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0], mer = L.w[WR][o0];
+    uint32_t valid = H >= 32 ? 0xffffffffu : ((1u << H) - 1u);
+    if (!(N & 1) && d >= H && H > 0) valid &= ~(1u << (H - 1));
+    uint32_t cand = 0u;
+    if (L.far[el] != 0) {
+      cand = valid;
+    } else {
+      const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
+#pragma unroll 2
+      for (int k = 1; k <= H; k += 2) {
+        const int o = o0 + k;
+        const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
+        const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
+        const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
+        v2f d2 = dx * dx;
+        d2 = __builtin_elementwise_fma(dy, dy, d2);
+        d2 = __builtin_elementwise_fma(dz, dz, d2);
+        const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
+        const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
+                                                 (v2f){P.band, P.band});
+        const uint32_t b0 = (d2.x <= rc.x) & (d2.x <= P.t10f), b1 = (d2.y <= rc.y) & (d2.y <= P.t10f);
+        cand |= (b0 | (b1 << 1)) << (k - 1);
+      }
+      cand &= valid;
+    }
+    while (cand) {  // exact decision, both drones of the pair
+      const int kb = __builtin_ctz(cand);
+      cand &= cand - 1;
+      int jd = d + kb + 1;
+      if (jd >= N) jd -= N;
+      const int k = el * N + jd;
+      const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
+      const double d2 = dot3b(rx, ry, rz, rx, ry, rz);
+      if (!(d2 <= P.T10)) continue;
+      if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) continue;
+      const double Or = L.r[k];
+      const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
+      bool ci, cj;
+      if (P.env_train) {
+        ci = cj = dis <= S.r + Or;
+      } else {  // rvo_inter.py:145-147: r - exp_radius + mr, evaluated from each side
+        ci = dis <= S.r - kExpRadius + Or;
+        cj = dis <= Or - kExpRadius + S.r;
+      }
+      if (ci) coll = true;
+      if (cj) atomicOr(&L.mask2[k], 1ull);
+    }
+  }
+  __syncthreads();
+  if (active && (L.mask2[lane] & 1ull)) coll = true;
+  return coll;
 }
 
 // building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
@@ -837,12 +904,13 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
 // One sweep of my env, by whichever pipeline the launch uses.  Called by every
 // thread of the workgroup (the wave pipeline synchronises inside).
-template <bool WAVE, bool ROWS>
+template <bool WAVE, bool ROWS, bool TOUCH = ROWS>
 __device__ __forceinline__ int do_sweep(const Params& P, const Lds& L, int tid, int el, int d,
                                         bool act, const Drone& S, const double a[3],
                                         bool zero_act, bool& flag, double& tmin,
                                         bool& collision) {
-  if (WAVE) return sweep_wave<ROWS>(P, L, tid, el, d, act, S, a, zero_act, flag, tmin, collision);
+  if (WAVE)
+    return sweep_wave<ROWS, TOUCH>(P, L, tid, el, d, act, S, a, zero_act, flag, tmin, collision);
   flag = false;
   tmin = __builtin_inf();
   return act ? sweep<ROWS>(P, L, tid, el * P.N, S, a, flag, tmin, collision) : 0;
@@ -1000,8 +1068,18 @@ env_kernel(const Params P) {
     exlen = real_len - route_len + 4;
     collision = building_hit(P, S);
   }
-  int kept = do_sweep<WAVE, true>(P, L, tid, el, d, active && !(P.ablate & 2), S, az, false, flag,
-                                  tmin, collision);
+  // In the fused auto-reset step an env that resets discards the step's VO rows
+  // (its observation is recomputed after the reset), so the wave pipeline first runs
+  // a collision-only sweep, settles the resets, and then sweeps ONCE for the rows -
+  // on the post-move state with the action, or on the post-reset state with 0.
+  constexpr bool LITE = WAVE && (MODE == kStepAutoReset);
+  int kept = 0;
+  if (LITE) {
+    if (collide_wave(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
+  } else {
+    kept = do_sweep<WAVE, true>(P, L, tid, el, d, active && !(P.ablate & 2), S, az, false, flag,
+                                tmin, collision);
+  }
   if (active) {
     if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
         p[2] > P.map[2])
@@ -1020,7 +1098,7 @@ env_kernel(const Params P) {
     if (do_reset) L.any_reset[el] = 1;
     __syncthreads();  // sweep B reads done; any_reset visible
     const bool env_reset = active && (L.any_reset[el] != 0);
-    if (active && !env_reset) {  // this env keeps the step's observation: write it now
+    if (!LITE && active && !env_reset) {  // this env keeps the step's observation: write it now
       if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
       L.kept[tid] = kept;
     }
@@ -1040,14 +1118,26 @@ env_kernel(const Params P) {
       else stage_f32(P, L, el, d, true, p, S.r);
     }
     __syncthreads();
-    // ir_gym.env_observation for every env that reset a drone (ir_gym.py:372-383)
     S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
     bool c2 = false;
-    const int kept_c = do_sweep<WAVE, true>(P, L, tid, el, d, env_reset && !(P.ablate & 4), S,
-                                            zero3, true, flag, tmin, c2);
-    if (env_reset) {
-      if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept_c);
-      L.kept[tid] = kept_c;
+    if (LITE) {
+      // rows for every env: ir_gym.observation_reward's VO part (env kept its state) or
+      // ir_gym.env_observation with action 0 (env reset a drone, ir_gym.py:372-383)
+      const double* aa = env_reset ? zero3 : az;
+      kept = do_sweep<WAVE, true, false>(P, L, tid, el, d, active && !(P.ablate & 4), S, aa,
+                                         env_reset, flag, tmin, c2);
+      if (active) {
+        if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+        L.kept[tid] = kept;
+      }
+    } else {
+      // ir_gym.env_observation for every env that reset a drone (ir_gym.py:372-383)
+      const int kept_c = do_sweep<WAVE, true>(P, L, tid, el, d, env_reset && !(P.ablate & 4), S,
+                                              zero3, true, flag, tmin, c2);
+      if (env_reset) {
+        if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept_c);
+        L.kept[tid] = kept_c;
+      }
     }
   } else if (active) {
     write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
