@@ -446,6 +446,12 @@ int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
   return RVO3D_OK;
 }
 
+int rvo3d_debug_stamps(rvo3d_env* h, unsigned long long* stamps) {
+  if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
+  h->P.dbg = stamps;
+  return RVO3D_OK;
+}
+
 int rvo3d_launch_info(rvo3d_env* h, int32_t* threads, int32_t* envs_per_block, int32_t* blocks,
                       int32_t* lds_bytes) {
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");

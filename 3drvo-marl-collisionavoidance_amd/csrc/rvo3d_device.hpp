@@ -78,6 +78,7 @@ struct Params {
   int32_t* wp_idx;
   uint8_t *arrive, *dest;
   uint32_t* err;
+  unsigned long long* dbg;  // diagnostics: per-workgroup s_memtime stamps [blocks][16], or null
   // per-call I/O
   const void* actions;
   float* obs;
@@ -85,6 +86,13 @@ struct Params {
   float* reward;
   uint8_t *done, *info, *finish, *reset_mask;
 };
+
+// diagnostic aid: phase stamps of lane 0, only when a stamp buffer is attached
+// (rvo3d_debug_stamps; tools/stamps.py)
+#define RVO3D_STAMP(i)                                                                  \
+  do {                                                                                  \
+    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 
 // ---- arithmetic primitives -------------------------------------------------
 __device__ __forceinline__ double sq(double x) { return x * x; }  // reference: pow(x, 2)
@@ -593,7 +601,8 @@ __device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lan
       // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
       const float gap = d2 - rs2;  // d^2 - R^2
       const int filt = (int)(gap >= P.x1_gap) & (int)(jprio == mprio);
-      const float K = 0.999998f * __builtin_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
+      // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
+      const float K = 0.999998f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
       const float K2 = K * K * P.x1_k2;
       const int kpos = K > 0.f;
       const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
@@ -932,6 +941,7 @@ env_kernel(const Params P) {
   const int lbase = el * N;
   const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
 
+  RVO3D_STAMP(0);
   double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
   double yaw = 0, pitch = 0, real_len = 0, max_dev = 0, extra_len = 0, route_len = 0;
   double cur[3] = {0, 0, 0}, prev[3] = {0, 0, 0}, dst[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dev = 0;
@@ -972,6 +982,7 @@ env_kernel(const Params P) {
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
   }
+  RVO3D_STAMP(1);
   double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
   if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
   const double zero3[3] = {0, 0, 0};
@@ -1003,12 +1014,14 @@ env_kernel(const Params P) {
     return;
   }
 
+  RVO3D_STAMP(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   double rew_k = 0;
   do_sweep<WAVE, false>(P, L, tid, el, d, active && !(P.ablate & 1), S, az, false, flag, tmin,
                         collision);
   if (active) rew_k = rvo_reward_k(dv, a, flag, tmin);
   __syncthreads();  // everyone is done with the pre-move LDS image
+  RVO3D_STAMP(3);
 
   // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490)
   if (active) {
@@ -1053,6 +1066,7 @@ env_kernel(const Params P) {
   __syncthreads();
   S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
+  RVO3D_STAMP(4);
   // ---- sweep B: ir_gym.observation_reward on the post-move state (ir_gym.py:156-254)
   bool do_reset = false, arrive_r = false, dest_r = false;
   const int waypoint_num = wpi;
@@ -1093,6 +1107,7 @@ env_kernel(const Params P) {
     do_reset = (MODE == kStepAutoReset) && (collision || f_dest);
   }
 
+  RVO3D_STAMP(5);
   if (MODE == kStepAutoReset) {
     if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
     if (do_reset) L.any_reset[el] = 1;
@@ -1119,6 +1134,7 @@ env_kernel(const Params P) {
     }
     __syncthreads();
     S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
+    RVO3D_STAMP(6);
     bool c2 = false;
     if (LITE) {
       // rows for every env: ir_gym.observation_reward's VO part (env kept its state) or
@@ -1144,6 +1160,7 @@ env_kernel(const Params P) {
     L.kept[tid] = kept;
   }
 
+  RVO3D_STAMP(7);
   if (active) {
     P.px[g] = p[0]; P.py[g] = p[1]; P.pz[g] = p[2];
     P.vx[g] = v[0]; P.vy[g] = v[1]; P.vz[g] = v[2];
@@ -1153,7 +1170,9 @@ env_kernel(const Params P) {
     P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
   }
   __syncthreads();  // L.kept complete
+  RVO3D_STAMP(8);
   if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
+  RVO3D_STAMP(9);
 }
 
 // ---- small state kernels -------------------------------------------------------

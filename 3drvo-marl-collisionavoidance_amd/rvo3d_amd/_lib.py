@@ -64,7 +64,7 @@ class StateView(C.Structure):
 SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
            "rvo3d_des_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
-           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_version", "rvo3d_last_error")
+           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_debug_stamps", "rvo3d_version", "rvo3d_last_error")
 
 _lib = None
 
@@ -94,6 +94,7 @@ def lib():
     L.rvo3d_set_state.argtypes = [vp] * 12
     L.rvo3d_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.rvo3d_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.rvo3d_debug_stamps.argtypes = [vp, vp]
     L.rvo3d_version.restype = i32
     L.rvo3d_last_error.restype = C.c_char_p
     for s in SYMBOLS:

@@ -150,6 +150,11 @@ int rvo3d_error_flags(rvo3d_env *h, uint32_t *flags, void *stream);
 int rvo3d_launch_info(rvo3d_env *h, int32_t *threads, int32_t *envs_per_block,
                       int32_t *blocks, int32_t *lds_bytes);
 
+/* Diagnostics: attach a device buffer of 16 uint64 per workgroup; lane 0 of every
+ * workgroup then stores s_memtime stamps at the kernel's phase boundaries
+ * (tools/stamps.py reads them).  NULL detaches.  Never attach it in a timed run. */
+int rvo3d_debug_stamps(rvo3d_env *h, unsigned long long *stamps);
+
 int rvo3d_version(void);
 const char *rvo3d_last_error(void);
 

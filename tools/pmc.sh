@@ -18,7 +18,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "env_kernel<2>" in r["Kernel_Name"]:
+        if "env_kernel<2" in r["Kernel_Name"]:
             a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 with open("$OUT/summary.txt", "w") as o:
     for k, (v, n) in sorted(agg.items()):
