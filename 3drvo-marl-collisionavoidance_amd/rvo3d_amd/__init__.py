@@ -12,6 +12,7 @@ HIP extension is missing, and every compute call needs a GPU.
 from ._lib import build_hip, lib, lib_path, RVO3DError  # noqa: F401
 from .batched_env import BatchedDroneEnv  # noqa: F401
 from .worlds import World, load_world_dir, synthetic_world, synthetic_actions  # noqa: F401
+from . import sharding  # noqa: F401
 
 __all__ = ["BatchedDroneEnv", "World", "load_world_dir", "synthetic_world",
            "synthetic_actions", "build_hip", "lib", "lib_path", "RVO3DError"]

@@ -89,25 +89,21 @@ def main():
     ap.add_argument("--no-autoreset", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from rvo3d_amd import BatchedDroneEnv, sharding, synthetic_actions, synthetic_world
+
+    rank, local_rank, world = sharding.rank_info()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from rvo3d_amd import BatchedDroneEnv, synthetic_actions, synthetic_world
+        dist = sharding.init_process_group("nccl", dev)  # nccl == RCCL on ROCm
 
     E, N, nm, nb = args.envs, args.drones, args.nm, args.buildings
     K, W = args.steps, args.warmup
     # shard = this rank's own envs: seed offset per rank
-    wld = synthetic_world(E, N, tuple(args.map), nb=nb, seed=1234 + rank)
+    wld = synthetic_world(E, N, tuple(args.map), nb=nb, seed=sharding.shard_seed(1234, rank))
     env = BatchedDroneEnv(wld, neighbors_num=nm, device=dev, action_decimals=2)
     # actions for every step, resident in HBM before the timed region (float32,
     # re-quantised on device to the 2-decimal fp64 values the reference steps with)
@@ -130,11 +126,7 @@ def main():
     for t in range(K):
         env.step(acts[(W + t) % n_act], autoreset=autoreset)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
 
     # kernel time: HIP events on the launch stream (torch's current stream), one pair per launch
     stream = torch.cuda.current_stream(dev)
