@@ -74,6 +74,8 @@ int carve(rvo3d_env* h) {
       {(void**)&P.max_dev, EN * 8}, {(void**)&P.extra_len, EN * 8},
       {(void**)&P.wp_idx, EN * 4}, {(void**)&P.arrive, EN}, {(void**)&P.dest, EN},
       {(void**)&P.err, 256},
+      {(void**)&P.row_iet, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 8},
+      {(void**)&P.row_pk, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 4},
   };
   size_t total = 0;
   for (auto& x : f) total += align_up(x.bytes, 256);
@@ -97,16 +99,33 @@ int check(rvo3d_env* h, bool need_world) {
   return RVO3D_OK;
 }
 
-template <int MODE>
-int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
-  if (P.wave_mode)
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, true>), dim3(h->blocks), dim3(h->threads), h->lds,
-                       s, P);
-  else
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, false>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
+template <int MODE, int NW>
+int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
+  hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+}
+
+template <int MODE>
+int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
+  switch (P.nw) {
+    case 1: return launch_nw<MODE, 1>(h, P, s);
+    case 2: return launch_nw<MODE, 2>(h, P, s);
+    case 4: return launch_nw<MODE, 4>(h, P, s);
+    default: return launch_nw<MODE, 8>(h, P, s);
+  }
+}
+
+template <int MODE, int NW>
+hipError_t allow_lds(int bytes) {
+  return hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW>,
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+template <int NW>
+bool allow_lds_all(int bytes) {
+  return allow_lds<rvo3d::kObserve, NW>(bytes) == hipSuccess &&
+         allow_lds<rvo3d::kStep, NW>(bytes) == hipSuccess &&
+         allow_lds<rvo3d::kStepAutoReset, NW>(bytes) == hipSuccess;
 }
 
 }  // namespace
@@ -172,21 +191,16 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     P.x1_cs2 = (float)(cs_out * cs_out);
   }
 
-  // Launch geometry: whole envs per workgroup.  When envs do not straddle waves
-  // (N divides 64) a workgroup is ONE wave: its barriers are free and every wave
-  // is scheduled independently; otherwise about 256 threads, waves of 64.
+  // Launch geometry: whole envs per workgroup.  N <= 64: a workgroup is ONE wave holding
+  // floor(64 / N) envs (its barriers are free, every wave is scheduled independently);
+  // larger envs get one workgroup of ceil(N / 64) waves each.
   const int N = P.N;
-  P.wave_mode = (N <= 64 && !std::getenv("RVO3D_GENERIC")) ? 1 : 0;
-  int epb = N >= 256 ? 1 : 256 / N;
-  if (P.wave_mode) epb = 64 / N;  // whole envs inside one wave; idle lanes when 64 % N != 0
+  int nw = (N + 63) / 64;
+  P.nw = nw <= 1 ? 1 : (nw <= 2 ? 2 : (nw <= 4 ? 4 : 8));
+  int epb = P.nw == 1 ? 64 / N : 1;
   if (epb > P.E) epb = P.E;
-  int threads = P.wave_mode ? 64 : (int)align_up((size_t)epb * N, 64);
-  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, P.wave_mode);
-  while (!P.wave_mode && lds > 64 * 1024 && epb > 1) {  // keep >= 2 workgroups per CU
-    epb = (epb + 1) / 2;
-    threads = (int)align_up((size_t)epb * N, 64);
-    lds = rvo3d::lds_bytes(threads, P.nm, epb, false);
-  }
+  const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)N, 64);
+  const size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, N, P.nw);
   if (lds > 160 * 1024) {
     delete h;
     return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");
@@ -215,23 +229,10 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;
   if (lds > 64 * 1024) {
-    hipError_t e1, e2, e3;
-    if (P.wave_mode) {
-      e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    } else {
-      e1 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kObserve, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e2 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStep, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      e3 = hipFuncSetAttribute((const void*)rvo3d::env_kernel<rvo3d::kStepAutoReset, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    }
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    const bool ok = P.nw == 1 ? allow_lds_all<1>((int)lds)
+                  : P.nw == 2 ? allow_lds_all<2>((int)lds)
+                  : P.nw == 4 ? allow_lds_all<4>((int)lds) : allow_lds_all<8>((int)lds);
+    if (!ok) {
       delete h;
       return fail(RVO3D_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }

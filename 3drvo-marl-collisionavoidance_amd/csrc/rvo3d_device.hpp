@@ -60,8 +60,8 @@ struct Params {
   float t10f;      // T10 + band, rounded up
   float band;      // fp32 error bound of a squared distance at <= 10.5 m
   float kdot;      // fp32 error bound of v.rel per unit |v|_1
-  // wave mode (N <= 64, one wave per workgroup): fp32 cone pre-filter (stage X1)
-  int wave_mode;
+  // fp32 cone pre-filter (stage X1)
+  int nw;          // ceil(N / 64) rounded up to a power of two: words per request mask
   float x1_gap;    // below this d2 - R^2 the cone filter is skipped (pair passes)
   float x1_k2;     // slack factor on K^2
   float x1_cs2;    // (cos-space error bound)^2: dp < 0 and dp^2 > cs2*d2*w2 is surely outside
@@ -78,6 +78,9 @@ struct Params {
   int32_t* wp_idx;
   uint8_t *arrive, *dest;
   uint32_t* err;
+  // kept VO rows of the sweep in flight, [nm][EN] each (touched only when a pair is flagged)
+  double* row_iet;     // 1 / (t + 0.2), ascending urgency
+  uint32_t* row_pk;    // (alpha * 100) << 16 | j
   unsigned long long* dbg;  // diagnostics: per-workgroup s_memtime stamps [blocks][16], or null
   // per-call I/O
   const void* actions;
@@ -231,67 +234,46 @@ struct PairOut {
 
 // ---- LDS views ---------------------------------------------------------------
 struct Lds {
-  double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T]
-  double* iet;                                   // [nm][T] kept VO rows, ascending urgency
-  uint32_t* pk;                                  // [nm][T] (alpha_c << 16) | j
+  double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T] fp64 image (exact stage)
   int* kept;                                     // [T] rows kept by the final sweep
   uint32_t* zc;                                  // [2T] per row: first / end 16-B chunk of its zero run
   int* any_reset;                                // [epb]
   int* far;                                      // [epb] a drone is outside the fp32 filter's bound
-  float *fx, *fy, *fz, *fr;                      // [epb * Npad] centred x, y, z, radius in fp32
-  int T, Npad;                                   // Npad = N rounded up to even (8-B pair reads)
-  // wave mode: fp32 image, each env's N slots stored twice ([el][2N]) so that
-  // neighbour d + k (mod N) is slot d + k; and the exact-stage request masks
-  float* w[12];                                  // x y z vx vy vz r kd ax ay az prio
-  unsigned long long* mask2;                     // [64] bit jd: run pair_eval(me, jd)
+  // fp32 image, each env's N slots stored twice ([el][2N]) so that neighbour
+  // d + k (mod N) is slot d + k; and the exact-stage request masks
+  float* w[12];                                  // x y z r [FL] (stored twice); vx vy vz kd ax ay az prio [FS]
+  unsigned long long* mask2;                     // [T][NW] bit j: run pair_eval(me, j)
+  int T;
 };
 
-__host__ __device__ inline int f32_len(int T, int epb) { return (T + epb + 3) & ~1; }
+// floats per fp32 array: two copies of every env of the workgroup
+__host__ __device__ inline int f32_len(int T, int N, int epb) { return (2 * epb * N + 3) & ~3; }
 
-__device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb, int N) {
+__device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb, int N,
+                                         int NW) {
   Lds L;
   double* d = reinterpret_cast<double*>(base);
   L.x = d; L.y = d + T; L.z = d + 2 * T; L.vx = d + 3 * T; L.vy = d + 4 * T; L.vz = d + 5 * T;
   L.r = d + 6 * T; L.prio = d + 7 * T;
-  L.iet = d + 8 * T;
-  L.pk = reinterpret_cast<uint32_t*>(L.iet + (size_t)nm * T);
-  L.kept = reinterpret_cast<int*>(L.pk + (size_t)nm * T);
+  L.mask2 = reinterpret_cast<unsigned long long*>(d + 8 * T);
+  L.kept = reinterpret_cast<int*>(L.mask2 + (size_t)T * NW);
   L.zc = reinterpret_cast<uint32_t*>(L.kept + T);
-  L.any_reset = reinterpret_cast<int*>(L.zc + 2 * T);
+  float* wf = reinterpret_cast<float*>(L.zc + 2 * T);
+  const int FL = f32_len(T, N, epb), FS = (epb * N + 3) & ~3;
+  // order: WX WY WZ WR doubled, then the single-copy arrays
+  L.w[0] = wf; L.w[1] = wf + FL; L.w[2] = wf + 2 * FL; L.w[6] = wf + 3 * FL;
+  float* ws = wf + 4 * (size_t)FL;
+  L.w[3] = ws; L.w[4] = ws + FS; L.w[5] = ws + 2 * FS; L.w[7] = ws + 3 * FS; L.w[8] = ws + 4 * FS;
+  L.w[9] = ws + 5 * FS; L.w[10] = ws + 6 * FS; L.w[11] = ws + 7 * FS;
+  L.any_reset = reinterpret_cast<int*>(ws + 8 * (size_t)FS);
   L.far = L.any_reset + epb;
-  const int FL = f32_len(T, epb);
-  // 8-B aligned: everything before is a multiple of 8 bytes when T is even (T is a multiple of 64)
-  L.fx = reinterpret_cast<float*>(L.far + epb + (epb & 1) * 0);
-  if ((reinterpret_cast<uintptr_t>(L.fx) & 7) != 0) L.fx += 1;
-  L.fy = L.fx + FL; L.fz = L.fy + FL; L.fr = L.fz + FL;
   L.T = T;
-  L.Npad = N + (N & 1);
-  // wave-mode arrays alias the generic fp32 region (the two modes never mix)
-  L.mask2 = reinterpret_cast<unsigned long long*>(L.fx);
-  float* wf = reinterpret_cast<float*>(L.mask2 + 64);
-  for (int k = 0; k < 12; ++k) L.w[k] = wf + 128 * k;
   return L;
 }
-__host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, bool wave = false) {
-  const size_t f32 = wave ? (size_t)(64 * 8 + 12 * 128 * 4) : (size_t)f32_len(T, epb) * 16;
-  return (size_t)T * 8 * 8 + (size_t)nm * T * 12 + (size_t)T * 12 + (size_t)epb * 8 + 8 + f32 + 16;
-}
-
-// Stage the fp32 image of one drone and raise the env's `far` flag when a
-// coordinate is outside the bound the bands assume (or is NaN).
-__device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el, int d,
-                                          bool active, const double p[3], double r) {
-  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
-  if (el < P.epb) {
-    const int k = el * L.Npad + d;
-    L.fx[k] = (float)cx; L.fy[k] = (float)cy; L.fz[k] = (float)cz; L.fr[k] = (float)r;
-    if (d == P.N - 1 && (P.N & 1)) {  // pad slot of an odd env: never a candidate
-      L.fx[k + 1] = 3.0e18f; L.fy[k + 1] = 3.0e18f; L.fz[k + 1] = 3.0e18f; L.fr[k + 1] = 0.0f;
-    }
-  }
-  const double cm = (double)P.cmax;
-  if (active && !(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
-    L.far[el] = 1;
+__host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, int N, int NW) {
+  (void)nm;
+  return (size_t)T * 8 * 8 + (size_t)T * NW * 8 + (size_t)T * 12 +
+         (size_t)f32_len(T, N, epb) * 16 + (size_t)((epb * N + 3) & ~3) * 32 + (size_t)epb * 8 + 16;
 }
 
 __device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
@@ -375,17 +357,19 @@ __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, co
 // most urgent in the order of list.sort(reverse=True, key=(-iet, min_dis)) (stable):
 // ascending iet, then descending min_dis, then ascending j; slot 0 = least urgent
 // kept.  The order is total, so the result does not depend on insertion order.
-__device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int tid, int lbase,
+__device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, int lbase,
                                           const Drone& S, const PairOut& po, int j, int kept) {
-  const int T = L.T;
+  const size_t T = (size_t)P.E * P.N;  // slot stride of the row scratch
+  double* const iet = P.row_iet + g;
+  uint32_t* const pk = P.row_pk + g;
   // position among kept rows: first slot whose row is more urgent than the new one
   int pos = kept;
   for (int s = 0; s < kept; ++s) {
-    const double ie = L.iet[s * T + tid];
+    const double ie = iet[s * T];
     bool new_first;  // new row sorts before slot s
     if (po.iet != ie) new_first = po.iet < ie;
     else {
-      const int js = (int)(L.pk[s * T + tid] & 0xffffu);
+      const int js = (int)(pk[s * T] & 0xffffu);
       const double mds = pair_md(S, lds_drone(L, lbase + js));
       new_first = (po.md != mds) ? (po.md > mds) : (j < js);
     }
@@ -394,110 +378,202 @@ __device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int tid
   const uint32_t packed = ((uint32_t)po.alpha_c << 16) | (uint32_t)j;
   if (kept < P.nm) {  // grow: shift [pos, kept) up by one
     for (int s = kept; s > pos; --s) {
-      L.iet[s * T + tid] = L.iet[(s - 1) * T + tid];
-      L.pk[s * T + tid] = L.pk[(s - 1) * T + tid];
+      iet[s * T] = iet[(s - 1) * T];
+      pk[s * T] = pk[(s - 1) * T];
     }
-    L.iet[pos * T + tid] = po.iet;
-    L.pk[pos * T + tid] = packed;
+    iet[pos * T] = po.iet;
+    pk[pos * T] = packed;
     ++kept;
   } else if (pos > 0) {  // full: drop slot 0 (least urgent), insert at pos-1
     for (int s = 0; s < pos - 1; ++s) {
-      L.iet[s * T + tid] = L.iet[(s + 1) * T + tid];
-      L.pk[s * T + tid] = L.pk[(s + 1) * T + tid];
+      iet[s * T] = iet[(s + 1) * T];
+      pk[s * T] = pk[(s + 1) * T];
     }
-    L.iet[(pos - 1) * T + tid] = po.iet;
-    L.pk[(pos - 1) * T + tid] = packed;
+    iet[(pos - 1) * T] = po.iet;
+    pk[(pos - 1) * T] = packed;
   }
   return kept;
 }
 
-// Stage G for up to 32 consecutive neighbours starting at fp32 slot `fb`:
-// bit jj is set when neighbour fb + jj is possibly in range and possibly
-// approaching (ROWS: or possibly touching).  Pure filter: stage X repeats
-// every test exactly.  Reads slot pairs (the slot behind an odd env is a pad).
-template <bool ROWS>
-__device__ __forceinline__ uint32_t gate32(const Params& P, const Lds& L, int fb, int cnt,
-                                           float mex, float mey, float mez, float mer, float fvx,
-                                           float fvy, float fvz, float kd) {
+// ===== the pair pipeline: whole envs per workgroup, fp32 filters, exact stage on request =====
+enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
+
+// fp32 image of one drone, written to both copies of its env segment.
+__device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el, int d,
+                                          bool active, const double p[3], const double v[3],
+                                          const double az[3], double r, double prio) {
+  if (!active) return;
+  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
+  const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
+  const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
+                         P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
+                         (float)az[0], (float)az[1], (float)az[2], (float)prio};
+  const int o = el * 2 * P.N + d, os = el * P.N + d;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    if (k == WX || k == WY || k == WZ || k == WR) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
+    else L.w[k][os] = val[k];
+  }
+  const double cm = (double)P.cmax;
+  if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
+    L.far[el] = 1;
+}
+
+// Offsets 1..N/2 a drone is responsible for, as NW words of 32 bits (bit b of word w =
+// offset 32w + b + 1).  With N even the offset N/2 belongs to the drones d < N/2 only.
+template <int NW>
+__device__ __forceinline__ void valid_offsets(int N, int d, uint32_t valid[NW]) {
+  const int H = N >> 1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int n = H - 32 * w;
+    valid[w] = n >= 32 ? 0xffffffffu : (n > 0 ? ((1u << n) - 1u) : 0u);
+  }
+  if (!(N & 1) && d >= H && H > 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (((H - 1) >> 5) == w) valid[w] &= ~(1u << ((H - 1) & 31));
+  }
+}
+
+// Stage G for the offsets of word w (packed fp32, two offsets per instruction): squared
+// distance to neighbour d + k against the threshold(s).  TOUCHONLY: possibly touching
+// (and in range); else: possibly in range.
+template <bool TOUCHONLY>
+__device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int o0, int w, int H,
+                                              float mex, float mey, float mez, float mer) {
   typedef float v2f __attribute__((ext_vector_type(2)));
-  const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez};
-  const v2f svx = {fvx, fvx}, svy = {fvy, fvy}, svz = {fvz, fvz};
+  const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
+  const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
   uint32_t m = 0u;
-  for (int jj = 0; jj < cnt; jj += 2) {
-    const v2f dx = *reinterpret_cast<const v2f*>(L.fx + fb + jj) - sx;
-    const v2f dy = *reinterpret_cast<const v2f*>(L.fy + fb + jj) - sy;
-    const v2f dz = *reinterpret_cast<const v2f*>(L.fz + fb + jj) - sz;
+#pragma unroll 2
+  for (int b = 0; b < kend; b += 2) {
+    const int o = o0 + 32 * w + b + 1;
+    const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
+    const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
+    const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
     v2f d2 = dx * dx;
     d2 = __builtin_elementwise_fma(dy, dy, d2);
     d2 = __builtin_elementwise_fma(dz, dz, d2);
-    v2f dt = svx * dx;
-    dt = __builtin_elementwise_fma(svy, dy, dt);
-    dt = __builtin_elementwise_fma(svz, dz, dt);
-    bool b0 = (d2.x <= P.t10f) && (dt.x > -kd);
-    bool b1 = (d2.y <= P.t10f) && (dt.y > -kd);
-    if (ROWS) {  // collisions count whatever the direction of motion
-      const v2f rs = *reinterpret_cast<const v2f*>(L.fr + fb + jj) + (v2f){mer, mer};
+    uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
+    if (TOUCHONLY) {
+      const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
       const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
                                                (v2f){P.band, P.band});
-      b0 = b0 || (d2.x <= rc.x);
-      b1 = b1 || (d2.y <= rc.y);
+      b0 &= (uint32_t)(d2.x <= rc.x);
+      b1 &= (uint32_t)(d2.y <= rc.y);
     }
-    m |= (b0 ? 1u : 0u) << jj;
-    m |= (b1 ? 2u : 0u) << jj;
+    m |= (b0 | (b1 << 1)) << b;
   }
-  if (cnt < 32) m &= (1u << cnt) - 1u;  // odd tail: the pad / next env's slot
   return m;
 }
 
-// Sweep over the other drones of my env (rvo_inter.preprocess gate,
-// rvo_inter.py:85-97, then config_vo_circle2 per in-range neighbour).
-//   ROWS = false: config_vo_reward (rvo_inter.py:63-83)  -> flag, tmin
-//   ROWS = true : config_vo_inf   (rvo_inter.py:20-61)   -> + collision, kept rows in LDS
-// Kept rows: the nm most urgent in the order of list.sort(reverse=True,
-// key=(-iet, min_dis)) (stable): ascending iet, then descending min_dis, then
-// ascending j; slot 0 = least urgent kept.  Returns the number kept.
-template <bool ROWS>
-__device__ __forceinline__ int sweep(const Params& P, const Lds& L, int tid, int lbase,
-                                     const Drone& S, const double a[3], bool& flag,
-                                     double& tmin, bool& collision) {
+// Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
+// drone whose index d satisfies j = d + k (mod N), 1 <= k <= N/2.
+//   stage G  (packed fp32, all offsets): possibly in range;
+//   stage X1 (fp32, candidates): possibly approaching / touching and a conservative
+//            cone pre-filter, for both directions; survivors request the exact
+//            evaluation from the owner (bit masks, LDS atomics);
+//   stage X2 (fp64, requested pairs only): pair_eval.
+// G and X1 only ever drop pairs that pair_eval would return "nothing" for.
+// NW = ceil(N / 64): words per request mask (64 drones) and per offset mask (32 offsets).
+template <int NW, bool ROWS, bool TOUCH>
+__device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
+                                         int g, bool active, const Drone& S, const double a[3],
+                                         bool zero_act, bool& flag, double& tmin,
+                                         bool& collision) {
   flag = false;
   tmin = __builtin_inf();
   int kept = 0;
-  const int N = P.N, T = L.T;
-  // per-lane constants of the fp32 filter
-  const int el = lbase / N, me_j = tid - lbase;
-  const int fbase = el * L.Npad;
-  const float mex = L.fx[fbase + me_j], mey = L.fy[fbase + me_j], mez = L.fz[fbase + me_j],
-              mer = L.fr[fbase + me_j];
-  const float fvx = (float)S.vx, fvy = (float)S.vy, fvz = (float)S.vz;
-  // v.rel > -kd is "possibly approaching"
-  const float kd = P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f;
-  const bool far = L.far[el] != 0;
-  for (int c0 = 0; c0 < N; c0 += 64) {
-    const int cn = (N - c0) < 64 ? (N - c0) : 64;
-    uint32_t mlo, mhi;
-    if (far) {  // a coordinate is outside the filter's bound: every neighbour is a candidate
-      const unsigned long long all = cn == 64 ? ~0ull : ((1ull << cn) - 1ull);
-      mlo = (uint32_t)all; mhi = (uint32_t)(all >> 32);
-    } else {  // stage G: two neighbours per packed instruction
-      mlo = gate32<ROWS>(P, L, fbase + c0, cn < 32 ? cn : 32, mex, mey, mez, mer, fvx, fvy, fvz, kd);
-      mhi = cn > 32 ? gate32<ROWS>(P, L, fbase + c0 + 32, cn - 32, mex, mey, mez, mer, fvx, fvy,
-                                   fvz, kd)
-                    : 0u;
+  const int N = P.N, H = N >> 1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) L.mask2[lane * NW + w] = 0ull;
+  __syncthreads();
+  unsigned long long m2r = 0ull;  // NW == 1: my own requests stay in a register
+  if (active) {
+    const int o0 = el * 2 * N + d, os0 = el * N + d;
+    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
+    const float mvx = L.w[WVX][os0], mvy = L.w[WVY][os0], mvz = L.w[WVZ][os0];
+    const float mer = L.w[WR][o0], mkd = L.w[WKD][os0], mprio = L.w[WPRIO][os0];
+    const float max_ = zero_act ? 0.f : L.w[WAX][os0], may = zero_act ? 0.f : L.w[WAY][os0],
+                maz = zero_act ? 0.f : L.w[WAZ][os0];
+    const bool far = L.far[el] != 0;
+    uint32_t valid[NW];
+    valid_offsets<NW>(N, d, valid);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      uint32_t cand = far ? valid[w]
+                          : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+      if (P.ablate & 64) cand = 0;
+      while (cand) {  // stage X1: both directions of one candidate pair
+        const int kb = __builtin_ctz(cand);
+        cand &= cand - 1;
+        const int off = 32 * w + kb + 1;
+        const int o = o0 + off;
+        int jd = d + off;
+        if (jd >= N) jd -= N;
+        const int oj_ = el * N + jd;  // the neighbour's slot in the single-copy arrays
+        // straight-line fp32; booleans are combined bitwise on purpose (no branches)
+        const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
+        const float jvx = L.w[WVX][oj_], jvy = L.w[WVY][oj_], jvz = L.w[WVZ][oj_];
+        const float jr = L.w[WR][o], jkd = L.w[WKD][oj_], jprio = L.w[WPRIO][oj_];
+        const float ajx = zero_act ? 0.f : L.w[WAX][oj_], ajy = zero_act ? 0.f : L.w[WAY][oj_],
+                    ajz = zero_act ? 0.f : L.w[WAZ][oj_];
+        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float rs = jr + mer;
+        const float rs2 = rs * rs;
+        const int touch = TOUCH & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
+        // possibly approaching, each direction (v.rel > -eps)
+        const int ai = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
+        const int aj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < jkd;
+        // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
+        const float gap = d2 - rs2;  // d^2 - R^2
+        const int filt = (int)(gap >= P.x1_gap) & (int)(jprio == mprio);
+        // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
+        const float K = 0.999998f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
+        const float K2 = K * K * P.x1_k2;
+        const int kpos = K > 0.f;
+        const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
+        // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
+        const float wix = 2.f * max_ - hx, wiy = 2.f * may - hy, wiz = 2.f * maz - hz;
+        const float dpi = __builtin_fmaf(dz, wiz, __builtin_fmaf(dy, wiy, dx * wix));
+        const float wi2 = __builtin_fmaf(wiz, wiz, __builtin_fmaf(wiy, wiy, wix * wix));
+        // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
+        const float wjx = 2.f * ajx - hx, wjy = 2.f * ajy - hy, wjz = 2.f * ajz - hz;
+        const float dpj = -__builtin_fmaf(dz, wjz, __builtin_fmaf(dy, wjy, dx * wjx));
+        const float wj2 = __builtin_fmaf(wjz, wjz, __builtin_fmaf(wjy, wjy, wjx * wjx));
+        const float cs = P.x1_cs2 * d2;
+        // surely outside: cos < -cs, or 0 <= cos < cos(alpha + delta) with slack
+        const int oi = ((int)(dpi < 0.f) & (int)(dpi * dpi > cs * wi2)) |
+                       ((int)(dpi >= 0.f) & kpos & (int)(dpi * dpi < wi2 * K2));
+        const int oj = ((int)(dpj < 0.f) & (int)(dpj * dpj > cs * wj2)) |
+                       ((int)(dpj >= 0.f) & kpos & (int)(dpj * dpj < wj2 * K2));
+        const int fr = far ? 1 : 0;
+        const bool pi = (fr | touch | (ai & ~(filt & oi))) & 1;
+        const bool pj = (fr | touch | (aj & ~(filt & oj))) & 1;
+        if (pi) {
+          if (NW == 1) m2r |= 1ull << jd;
+          else atomicOr(&L.mask2[lane * NW + (jd >> 6)], 1ull << (jd & 63));
+        }
+        if (pj) atomicOr(&L.mask2[(el * N + jd) * NW + (d >> 6)], 1ull << (d & 63));
+      }
     }
-    unsigned long long mask = ((unsigned long long)mhi << 32) | mlo;
-    if (me_j >= c0 && me_j < c0 + 64) mask &= ~(1ull << (me_j - c0));  // j != i (ir_gym.py:56)
-    while (mask) {  // stage X: exact, candidates only
-      const int jj = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int j = c0 + jj;
-      const PairOut po = pair_eval(P, S, L, lbase + j, a);
-      if (ROWS && po.collision) collision = true;
-      if (po.flag) {
-        flag = true;
-        if (po.t < tmin) tmin = po.t;
-        if (ROWS && P.nm > 0) {
-          kept = insert_row(P, L, tid, lbase, S, po, j, kept);
+  }
+  __syncthreads();
+  if (active && !(P.ablate & 32)) {
+    const int lbase = el * N;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
+      while (m2) {  // stage X2: exact, requested pairs only
+        const int j = 64 * w + __builtin_ctzll(m2);
+        m2 &= m2 - 1;
+        const PairOut po = pair_eval(P, S, L, lbase + j, a);
+        if (TOUCH && po.collision) collision = true;
+        if (po.flag) {
+          flag = true;
+          if (po.t < tmin) tmin = po.t;
+          if (ROWS && P.nm > 0) kept = insert_row(P, L, g, lbase, S, po, j, kept);
         }
       }
     }
@@ -505,211 +581,54 @@ __device__ __forceinline__ int sweep(const Params& P, const Lds& L, int tid, int
   return kept;
 }
 
-// ===== wave mode (N <= 64: whole envs inside one wave, workgroup = one wave) =====
-enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
-
-// fp32 image of one drone, written to both copies of its env segment.
-__device__ __forceinline__ void stage_wave(const Params& P, const Lds& L, int el, int d,
-                                           bool active, const double p[3], const double v[3],
-                                           const double az[3], double r, double prio) {
-  if (!active) return;
-  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
-  const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
-  const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
-                         P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
-                         (float)az[0], (float)az[1], (float)az[2], (float)prio};
-  const int o = el * 2 * P.N + d;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
-  const double cm = (double)P.cmax;
-  if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
-    L.far[el] = 1;
-}
-
-// Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
-// lane whose drone index d satisfies j = d + k (mod N), 1 <= k <= N/2.
-//   stage G  (packed fp32, all offsets): possibly in range and (possibly approaching
-//            in either direction, or possibly touching);
-//   stage X1 (fp32, candidates): conservative cone pre-filter for both directions;
-//            survivors request the exact evaluation from the owner (own register /
-//            LDS bit mask of the neighbour);
-//   stage X2 (fp64, requested pairs only): pair_eval, exactly as the generic path.
-// G and X1 only ever drop pairs that pair_eval would return "nothing" for.
-template <bool ROWS, bool TOUCH>
-__device__ __forceinline__ int sweep_wave(const Params& P, const Lds& L, int lane, int el, int d,
-                                          bool active, const Drone& S, const double a[3],
-                                          bool zero_act, bool& flag, double& tmin,
-                                          bool& collision) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  flag = false;
-  tmin = __builtin_inf();
-  int kept = 0;
-  const int N = P.N, H = N >> 1, T = L.T;
-  L.mask2[lane] = 0ull;
-  __syncthreads();
-  unsigned long long m2 = 0ull;
-  if (active) {
-    const int o0 = el * 2 * N + d;
-    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
-    const float mvx = L.w[WVX][o0], mvy = L.w[WVY][o0], mvz = L.w[WVZ][o0];
-    const float mer = L.w[WR][o0], mkd = L.w[WKD][o0], mprio = L.w[WPRIO][o0];
-    const float max_ = zero_act ? 0.f : L.w[WAX][o0], may = zero_act ? 0.f : L.w[WAY][o0],
-                maz = zero_act ? 0.f : L.w[WAZ][o0];
-    const bool far = L.far[el] != 0;
-    uint32_t valid = H >= 32 ? 0xffffffffu : ((1u << H) - 1u);
-    if (!(N & 1) && d >= H && H > 0) valid &= ~(1u << (H - 1));  // offset N/2 belongs to d < N/2
-    uint32_t cand = 0u;
-    if (far) {
-      cand = valid;
-    } else {
-      const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez};
-#pragma unroll 2
-      for (int k = 1; k <= H; k += 2) {  // stage G: offsets k and k + 1
-        const int o = o0 + k;
-        const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
-        const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
-        const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
-        v2f d2 = dx * dx;
-        d2 = __builtin_elementwise_fma(dy, dy, d2);
-        d2 = __builtin_elementwise_fma(dz, dz, d2);
-        // possibly in range (covers "possibly touching" as long as R^2 + band <= t10f)
-        const uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
-        cand |= (b0 | (b1 << 1)) << (k - 1);
-      }
-      cand &= valid;
-    }
-    if (P.ablate & 64) cand = 0;
-    while (cand) {  // stage X1: both directions of one candidate pair
-      const int kb = __builtin_ctz(cand);
-      cand &= cand - 1;
-      const int o = o0 + kb + 1;
-      int jd = d + kb + 1;
-      if (jd >= N) jd -= N;
-      // straight-line fp32; booleans are combined bitwise on purpose (no branches)
-      const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
-      const float jvx = L.w[WVX][o], jvy = L.w[WVY][o], jvz = L.w[WVZ][o];
-      const float jr = L.w[WR][o], jkd = L.w[WKD][o], jprio = L.w[WPRIO][o];
-      const float ajx = zero_act ? 0.f : L.w[WAX][o], ajy = zero_act ? 0.f : L.w[WAY][o],
-                  ajz = zero_act ? 0.f : L.w[WAZ][o];
-      const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-      const float rs = jr + mer;
-      const float rs2 = rs * rs;
-      const int touch = TOUCH & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
-      // possibly approaching, each direction (v.rel > -eps)
-      const int ai = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
-      const int aj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < jkd;
-      // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
-      const float gap = d2 - rs2;  // d^2 - R^2
-      const int filt = (int)(gap >= P.x1_gap) & (int)(jprio == mprio);
-      // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
-      const float K = 0.999998f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
-      const float K2 = K * K * P.x1_k2;
-      const int kpos = K > 0.f;
-      const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
-      // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
-      const float wix = 2.f * max_ - hx, wiy = 2.f * may - hy, wiz = 2.f * maz - hz;
-      const float dpi = __builtin_fmaf(dz, wiz, __builtin_fmaf(dy, wiy, dx * wix));
-      const float wi2 = __builtin_fmaf(wiz, wiz, __builtin_fmaf(wiy, wiy, wix * wix));
-      // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
-      const float wjx = 2.f * ajx - hx, wjy = 2.f * ajy - hy, wjz = 2.f * ajz - hz;
-      const float dpj = -__builtin_fmaf(dz, wjz, __builtin_fmaf(dy, wjy, dx * wjx));
-      const float wj2 = __builtin_fmaf(wjz, wjz, __builtin_fmaf(wjy, wjy, wjx * wjx));
-      const float cs = P.x1_cs2 * d2;
-      // surely outside: cos < -cs, or 0 <= cos < cos(alpha + delta) with slack
-      const int oi = ((int)(dpi < 0.f) & (int)(dpi * dpi > cs * wi2)) |
-                     ((int)(dpi >= 0.f) & kpos & (int)(dpi * dpi < wi2 * K2));
-      const int oj = ((int)(dpj < 0.f) & (int)(dpj * dpj > cs * wj2)) |
-                     ((int)(dpj >= 0.f) & kpos & (int)(dpj * dpj < wj2 * K2));
-      const int fr = far ? 1 : 0;
-      const bool pi = (fr | touch | (ai & ~(filt & oi))) & 1;
-      const bool pj = (fr | touch | (aj & ~(filt & oj))) & 1;
-      if (pi) m2 |= 1ull << jd;
-      if (pj) atomicOr(&L.mask2[el * N + jd], 1ull << d);
-    }
-  }
-  __syncthreads();
-  if (active && !(P.ablate & 32)) {
-    m2 |= L.mask2[lane];
-    const int lbase = el * N;
-    while (m2) {  // stage X2: exact, requested pairs only
-      const int j = __builtin_ctzll(m2);
-      m2 &= m2 - 1;
-      const PairOut po = pair_eval(P, S, L, lbase + j, a);
-      if (TOUCH && po.collision) collision = true;
-      if (po.flag) {
-        flag = true;
-        if (po.t < tmin) tmin = po.t;
-        if (ROWS && P.nm > 0) kept = insert_row(P, L, lane, lbase, S, po, j, kept);
-      }
-    }
-  }
-  return kept;
-}
-
-// Collision-only sweep (wave mode): exactly the collision_flag part of
-// rvo_inter.config_vo_inf (rvo_inter.py:40-48) - a neighbour inside the 10 m gate,
-// not at the very same position, with dis <= r + mr (env_train) - for every drone
-// of the env.  Each unordered pair is tested once; the fp32 stage only selects
-// pairs that are possibly touching, the decision itself is fp64.
-__device__ __forceinline__ bool collide_wave(const Params& P, const Lds& L, int lane, int el,
-                                             int d, bool active, const Drone& S) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
+// Collision-only sweep: exactly the collision_flag part of rvo_inter.config_vo_inf
+// (rvo_inter.py:40-48) - a neighbour inside the 10 m gate, not at the very same
+// position, with dis <= r + mr (env_train) - for every drone of the env.  Each
+// unordered pair is tested once; the fp32 stage only selects pairs that are possibly
+// touching, the decision itself is fp64.
+template <int NW>
+__device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int lane, int el,
+                                            int d, bool active, const Drone& S) {
   const int N = P.N, H = N >> 1;
-  L.mask2[lane] = 0ull;
+  L.mask2[lane * NW] = 0ull;
   __syncthreads();
   bool coll = false;
   if (active) {
     const int o0 = el * 2 * N + d;
     const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0], mer = L.w[WR][o0];
-    uint32_t valid = H >= 32 ? 0xffffffffu : ((1u << H) - 1u);
-    if (!(N & 1) && d >= H && H > 0) valid &= ~(1u << (H - 1));
-    uint32_t cand = 0u;
-    if (L.far[el] != 0) {
-      cand = valid;
-    } else {
-      const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
-#pragma unroll 2
-      for (int k = 1; k <= H; k += 2) {
-        const int o = o0 + k;
-        const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
-        const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
-        const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
-        v2f d2 = dx * dx;
-        d2 = __builtin_elementwise_fma(dy, dy, d2);
-        d2 = __builtin_elementwise_fma(dz, dz, d2);
-        const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
-        const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
-                                                 (v2f){P.band, P.band});
-        const uint32_t b0 = (d2.x <= rc.x) & (d2.x <= P.t10f), b1 = (d2.y <= rc.y) & (d2.y <= P.t10f);
-        cand |= (b0 | (b1 << 1)) << (k - 1);
+    const bool far = L.far[el] != 0;
+    uint32_t valid[NW];
+    valid_offsets<NW>(N, d, valid);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      uint32_t cand = far ? valid[w]
+                          : (gate_word<true>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+      while (cand) {  // exact decision, both drones of the pair
+        const int kb = __builtin_ctz(cand);
+        cand &= cand - 1;
+        int jd = d + 32 * w + kb + 1;
+        if (jd >= N) jd -= N;
+        const int k = el * N + jd;
+        const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
+        const double d2 = dot3b(rx, ry, rz, rx, ry, rz);
+        if (!(d2 <= P.T10)) continue;
+        if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) continue;
+        const double Or = L.r[k];
+        const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
+        bool ci, cj;
+        if (P.env_train) {
+          ci = cj = dis <= S.r + Or;
+        } else {  // rvo_inter.py:145-147: r - exp_radius + mr, evaluated from each side
+          ci = dis <= S.r - kExpRadius + Or;
+          cj = dis <= Or - kExpRadius + S.r;
+        }
+        if (ci) coll = true;
+        if (cj) atomicOr(&L.mask2[k * NW], 1ull);
       }
-      cand &= valid;
-    }
-    while (cand) {  // exact decision, both drones of the pair
-      const int kb = __builtin_ctz(cand);
-      cand &= cand - 1;
-      int jd = d + kb + 1;
-      if (jd >= N) jd -= N;
-      const int k = el * N + jd;
-      const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
-      const double d2 = dot3b(rx, ry, rz, rx, ry, rz);
-      if (!(d2 <= P.T10)) continue;
-      if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) continue;
-      const double Or = L.r[k];
-      const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
-      bool ci, cj;
-      if (P.env_train) {
-        ci = cj = dis <= S.r + Or;
-      } else {  // rvo_inter.py:145-147: r - exp_radius + mr, evaluated from each side
-        ci = dis <= S.r - kExpRadius + Or;
-        cj = dis <= Or - kExpRadius + S.r;
-      }
-      if (ci) coll = true;
-      if (cj) atomicOr(&L.mask2[k], 1ull);
     }
   }
   __syncthreads();
-  if (active && (L.mask2[lane] & 1ull)) coll = true;
+  if (active && (L.mask2[lane * NW] & 1ull)) coll = true;
   return coll;
 }
 
@@ -755,7 +674,7 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
     for (int k = 0; k < 12; ++k) o[k] = f[k];
   }
   for (int s = 0; s < kept; ++s) {
-    const uint32_t pk = L.pk[s * L.T + tid];
+    const uint32_t pk = P.row_pk[(size_t)s * P.E * P.N + g];
     const int j = (int)(pk & 0xffffu);
     const Drone O = lds_drone(L, lbase + j);
     const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
@@ -766,7 +685,7 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
     row[3] = O.x - S.x; row[4] = O.y - S.y; row[5] = O.z - S.z;
     row[6] = (double)(pk >> 16) / 100.0;
     row[7] = pair_md(S, O);
-    row[8] = L.iet[s * L.T + tid];
+    row[8] = P.row_iet[(size_t)s * P.E * P.N + g];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       bad |= !finite_d(row[k]);
@@ -911,27 +830,12 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 #define RVO3D_WAVES_ATTR
 #endif
 
-// One sweep of my env, by whichever pipeline the launch uses.  Called by every
-// thread of the workgroup (the wave pipeline synchronises inside).
-template <bool WAVE, bool ROWS, bool TOUCH = ROWS>
-__device__ __forceinline__ int do_sweep(const Params& P, const Lds& L, int tid, int el, int d,
-                                        bool act, const Drone& S, const double a[3],
-                                        bool zero_act, bool& flag, double& tmin,
-                                        bool& collision) {
-  if (WAVE)
-    return sweep_wave<ROWS, TOUCH>(P, L, tid, el, d, act, S, a, zero_act, flag, tmin, collision);
-  flag = false;
-  tmin = __builtin_inf();
-  return act ? sweep<ROWS>(P, L, tid, el * P.N, S, a, flag, tmin, collision) : 0;
-}
-
 // The whole environment step, one launch.
-template <int MODE, bool WAVE>
-__global__ void __launch_bounds__(WAVE ? 64 : kMaxThreads) RVO3D_WAVES_ATTR
-env_kernel(const Params P) {
+template <int MODE, int NW>
+__global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, T = blockDim.x, N = P.N;
-  const Lds L = carve_lds(smem, T, P.nm, P.epb, N);
+  const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
   const int el = tid / N;
   const int d = tid - el * N;
   const int e0 = blockIdx.x * P.epb;
@@ -993,8 +897,7 @@ env_kernel(const Params P) {
   L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
   L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
   L.r[tid] = S.r; L.prio[tid] = S.prio;
-  if (WAVE) stage_wave(P, L, el, d, active, p, v, az, S.r, S.prio);
-  else stage_f32(P, L, el, d, active, p, S.r);
+  stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
   __syncthreads();
   S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
@@ -1002,8 +905,8 @@ env_kernel(const Params P) {
   double tmin;
 
   if (MODE == kObserve) {
-    const int kept = do_sweep<WAVE, true>(P, L, tid, el, d, active, S, zero3, true, flag, tmin,
-                                          collision);
+    const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
+                                               tmin, collision);
     if (active) {
       write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
       L.kept[tid] = kept;
@@ -1017,8 +920,8 @@ env_kernel(const Params P) {
   RVO3D_STAMP(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   double rew_k = 0;
-  do_sweep<WAVE, false>(P, L, tid, el, d, active && !(P.ablate & 1), S, az, false, flag, tmin,
-                        collision);
+  sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
+                              tmin, collision);
   if (active) rew_k = rvo_reward_k(dv, a, flag, tmin);
   __syncthreads();  // everyone is done with the pre-move LDS image
   RVO3D_STAMP(3);
@@ -1061,8 +964,7 @@ env_kernel(const Params P) {
   }
   L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
   L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
-  if (WAVE) stage_wave(P, L, el, d, active, p, v, az, S.r, S.prio);
-  else stage_f32(P, L, el, d, active, p, S.r);
+  stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
   __syncthreads();
   S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
@@ -1086,13 +988,13 @@ env_kernel(const Params P) {
   // (its observation is recomputed after the reset), so the wave pipeline first runs
   // a collision-only sweep, settles the resets, and then sweeps ONCE for the rows -
   // on the post-move state with the action, or on the post-reset state with 0.
-  constexpr bool LITE = WAVE && (MODE == kStepAutoReset);
+  constexpr bool LITE = (MODE == kStepAutoReset);
   int kept = 0;
   if (LITE) {
-    if (collide_wave(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
+    if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
   } else {
-    kept = do_sweep<WAVE, true>(P, L, tid, el, d, active && !(P.ablate & 2), S, az, false, flag,
-                                tmin, collision);
+    kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
+                                     flag, tmin, collision);
   }
   if (active) {
     if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
@@ -1129,8 +1031,7 @@ env_kernel(const Params P) {
       if (dev > max_dev) max_dev = dev;
       L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
       L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
-      if (WAVE) stage_wave(P, L, el, d, true, p, v, az, S.r, S.prio);
-      else stage_f32(P, L, el, d, true, p, S.r);
+      stage_f32(P, L, el, d, true, p, v, az, S.r, S.prio);
     }
     __syncthreads();
     S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
@@ -1140,16 +1041,16 @@ env_kernel(const Params P) {
       // rows for every env: ir_gym.observation_reward's VO part (env kept its state) or
       // ir_gym.env_observation with action 0 (env reset a drone, ir_gym.py:372-383)
       const double* aa = env_reset ? zero3 : az;
-      kept = do_sweep<WAVE, true, false>(P, L, tid, el, d, active && !(P.ablate & 4), S, aa,
-                                         env_reset, flag, tmin, c2);
+      kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
+                                        env_reset, flag, tmin, c2);
       if (active) {
         if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
         L.kept[tid] = kept;
       }
     } else {
       // ir_gym.env_observation for every env that reset a drone (ir_gym.py:372-383)
-      const int kept_c = do_sweep<WAVE, true>(P, L, tid, el, d, env_reset && !(P.ablate & 4), S,
-                                              zero3, true, flag, tmin, c2);
+      const int kept_c = sweep_env<NW, true, true>(P, L, tid, el, d, g, env_reset && !(P.ablate & 4),
+                                                   S, zero3, true, flag, tmin, c2);
       if (env_reset) {
         if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept_c);
         L.kept[tid] = kept_c;
