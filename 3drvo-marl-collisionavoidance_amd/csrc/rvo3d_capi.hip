@@ -200,7 +200,8 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   int epb = P.nw == 1 ? 64 / N : 1;
   if (epb > P.E) epb = P.E;
   const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)N, 64);
-  const size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, N, P.nw);
+  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, N, P.nw);
+  if (const char* pad = std::getenv("RVO3D_LDS_PAD")) lds += (size_t)std::atoi(pad);  // diagnostics: cap occupancy
   if (lds > 160 * 1024) {
     delete h;
     return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");

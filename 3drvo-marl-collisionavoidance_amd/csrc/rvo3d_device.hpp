@@ -446,7 +446,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
   const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
   const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
   uint32_t m = 0u;
-#pragma unroll 2
+#pragma unroll 8
   for (int b = 0; b < kend; b += 2) {
     const int o = o0 + 32 * w + b + 1;
     const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
