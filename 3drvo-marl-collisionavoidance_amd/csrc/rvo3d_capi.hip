@@ -361,6 +361,25 @@ int rvo3d_step(rvo3d_env* h, const void* actions, int32_t action_dtype, float* o
                      false, stream);
 }
 
+static int step_policy_common(rvo3d_env* h, const float* a_inc, float acceler, float* obs,
+                              int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
+                              uint8_t* finish, uint8_t* reset_mask, bool autoreset, void* stream) {
+  if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
+  h->P.action_mode = 1;
+  h->P.acceler = acceler;
+  const int rc = step_common(h, a_inc, RVO3D_F32, obs, vo_count, reward, done, info, finish,
+                             reset_mask, autoreset, stream);
+  h->P.action_mode = 0;
+  return rc;
+}
+
+int rvo3d_step_policy(rvo3d_env* h, const float* a_inc, float acceler, float* obs,
+                      int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
+                      uint8_t* finish, uint8_t* reset_mask, int32_t autoreset, void* stream) {
+  return step_policy_common(h, a_inc, acceler, obs, vo_count, reward, done, info, finish,
+                            reset_mask, autoreset != 0, stream);
+}
+
 int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
                          int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                          uint8_t* finish, uint8_t* reset_mask, void* stream) {

@@ -45,6 +45,8 @@ constexpr double kSinD = 1.0000000000e-4;          // >= sin(1e-4)
 struct Params {
   int E, N, P, nb, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
+  int action_mode;    // 0: absolute action; 1: policy increment (trainer glue, multi_ppo.py:196-205)
+  float acceler;      // ir_gym.acceler as numpy sees it next to a float32 array (float32)
   int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
@@ -868,17 +870,30 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       npts = P.n_points[g];
       f_arrive = P.arrive[g] != 0; f_dest = P.dest[g] != 0;
       load_wp(P, g, npts - 1, dst);
-      if (P.action_f64) {
-        const double* A = static_cast<const double*>(P.actions) + (size_t)g * 3;
-        a[0] = A[0]; a[1] = A[1]; a[2] = A[2];
-      } else {
+      if (P.action_mode == 1) {
+        // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:
+        //   a_inc = np.round(sample, 2)                  float32: rint(a * 100f) / 100f
+        //   abs   = np.round(acceler * a_inc + vel, 2)   float32 product, widened, + float64
         const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
-        a[0] = (double)A[0]; a[1] = (double)A[1]; a[2] = (double)A[2];
-      }
-      if (P.act_scale > 0) {
-        a[0] = __builtin_rint(a[0] * P.act_scale) / P.act_scale;
-        a[1] = __builtin_rint(a[1] * P.act_scale) / P.act_scale;
-        a[2] = __builtin_rint(a[2] * P.act_scale) / P.act_scale;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float r = __builtin_rintf(A[k] * 100.0f) / 100.0f;
+          const double x = (double)(P.acceler * r) + v[k];
+          a[k] = __builtin_rint(x * 100.0) / 100.0;
+        }
+      } else {
+        if (P.action_f64) {
+          const double* A = static_cast<const double*>(P.actions) + (size_t)g * 3;
+          a[0] = A[0]; a[1] = A[1]; a[2] = A[2];
+        } else {
+          const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
+          a[0] = (double)A[0]; a[1] = (double)A[1]; a[2] = (double)A[2];
+        }
+        if (P.act_scale > 0) {
+          a[0] = __builtin_rint(a[0] * P.act_scale) / P.act_scale;
+          a[1] = __builtin_rint(a[1] * P.act_scale) / P.act_scale;
+          a[2] = __builtin_rint(a[2] * P.act_scale) / P.act_scale;
+        }
       }
     }
     // drone.dronestate on the pre-move state (drone.py:254-263)

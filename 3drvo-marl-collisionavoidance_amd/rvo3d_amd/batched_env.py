@@ -112,6 +112,21 @@ class BatchedDroneEnv:
         self._last_actions = a  # keep the borrowed buffer alive until the launch ran
         return self.obs, self.vo_count, self.reward, self.done, self.info, self.finish
 
+    def step_policy(self, a_inc, autoreset: bool = True):
+        """Step from raw policy samples: the trainer's glue (multi_ppo.py:196-210,
+        a = round(a_inc, 2); action = round(acceler * a + vel, 2)) runs on the device.
+        a_inc: float32 [E, N, 3]."""
+        a = torch.as_tensor(a_inc, device=self.device).to(torch.float32).contiguous()
+        if tuple(a.shape) != (self.E, self.N, 3):
+            raise AssertionError(f"a_inc must have shape ({self.E}, {self.N}, 3)")
+        rc = _lib.lib().rvo3d_step_policy(
+            self._h, _ptr(a), C.c_float(self.acceler), _ptr(self.obs), _ptr(self.vo_count),
+            _ptr(self.reward), _ptr(self.done), _ptr(self.info), _ptr(self.finish),
+            _ptr(self.reset_mask), 1 if autoreset else 0, self._stream())
+        _lib.check(rc, "rvo3d_step_policy")
+        self._last_actions = a
+        return self.obs, self.vo_count, self.reward, self.done, self.info, self.finish
+
     def reset(self, env_mask=None):
         m = None
         if env_mask is not None:

@@ -125,6 +125,16 @@ int rvo3d_step_autoreset(rvo3d_env *h, const void *actions, int32_t action_dtype
                          uint8_t *info, uint8_t *finish, uint8_t *reset_mask,
                          void *stream);
 
+/* The step driven by raw policy samples: the trainer's glue between `ac.step` and
+ * `env.drone_step` (train/policy/multi_ppo.py:196-210) runs on the device, in numpy's
+ * own types:  a = np.round(a_inc, 2) (float32);  action = np.round(acceler * a +
+ * drone.vel, 2) (float32 product widened, float64 sum).  a_inc [E][N][3] float32;
+ * acceler = ir_gym.acceler (0.5).  autoreset != 0 fuses the reset protocol as
+ * rvo3d_step_autoreset does (reset_mask nullable). */
+int rvo3d_step_policy(rvo3d_env *h, const float *a_inc, float acceler, float *obs,
+                      int32_t *vo_count, float *reward, uint8_t *done, uint8_t *info,
+                      uint8_t *finish, uint8_t *reset_mask, int32_t autoreset, void *stream);
+
 /* ir_gym.cal_des_list (ir_gym.py:44): desired velocity, des_vel [E][N][3] f64. */
 int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
 

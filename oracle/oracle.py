@@ -103,8 +103,11 @@ class OracleEnv:
         self._keep = (wp, npts, bld, ms, rad, pri)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None:
+            try:
+                _lib.orc_destroy(self._h)
+            except Exception:
+                pass
             self._h = None
 
     def _outs(self):

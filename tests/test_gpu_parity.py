@@ -257,3 +257,46 @@ def test_mdin_list_api_config1_world4():
     with pytest.raises(AssertionError):
         env.drone_step([[0, 0, 0]] * 4)   # python lists are rejected (drone.py:98-101)
     env.close()
+
+
+def test_step_policy_trainer_glue():
+    """abs_action = np.round(acceler * np.round(a_inc, 2) + vel, 2)
+    (multi_ppo.py:196-205) computed on the device from raw float32 samples must equal
+    numpy's own arithmetic fed to the oracle."""
+    world = synthetic_world(128, 16, (20, 20, 8), seed=11)
+    E, N, _ = world.shape
+    env = BatchedDroneEnv(world)
+    ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, threads=8)
+    env.observe(); ref.observe()
+    rng = np.random.default_rng(3)
+    tl = Tally()
+    rows = 0
+    tainted = np.zeros((E, 1), bool)  # envs whose action itself was decided by a last bit
+    for t in range(40):
+        a_inc = rng.normal(0, 0.6, (E, N, 3)).clip(-1, 1).astype(np.float32)
+        vel = ref.get_state()["vel"]
+        gvel = env.get_state()["vel"].cpu().numpy()
+        a2 = np.round(a_inc, 2)                      # float32, as in the trainer
+        abs_action = np.round(env.acceler * a2 + vel, 2)
+        assert a2.dtype == np.float32 and abs_action.dtype == np.float64
+        obs, cnt, rew, done, info, fin = env.step_policy(torch.from_numpy(a_inc).cuda(), autoreset=True)
+        ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(abs_action)
+        # The glue's own rounding is a decision too: 0.5 * a + vel can sit on a .5 tie
+        # (vel is a decimal when pitch = +-90 deg) where the last bit of vel - libm noise
+        # of sin/cos - decides.  An env whose two runs rounded differently has a
+        # different future and leaves the comparison.
+        tainted |= (np.round(env.acceler * a2 + gvel, 2) != abs_action).any(axis=(1, 2))[:, None]
+        mg = np.where(tainted, 0.0, ref.margin())
+        tl.count(mg)
+        tl.check(f"done t={t}", done.cpu().numpy() == rd, mg)
+        tl.check(f"finish t={t}", fin.cpu().numpy() == rf, mg)
+        tl.check(f"vo_count t={t}", cnt.cpu().numpy() == rcnt, mg)
+        tl.check(f"obs t={t}", eq_nan(obs.cpu().numpy(), ro.astype(np.float32)), mg)
+        tl.check(f"reward t={t}", eq_nan(rew.cpu().numpy(), rr.astype(np.float32)), mg)
+        rows += int(rcnt.sum())
+    assert tainted.mean() < 0.2
+    s, rs = env.get_state(), ref.get_state()
+    ok_env = ~tainted[:, 0]
+    np.testing.assert_allclose(s["pos"].cpu().numpy()[ok_env], rs["pos"][ok_env], rtol=1e-9, atol=1e-9)
+    assert rows > 0
+    env.close()
