@@ -1,0 +1,268 @@
+"""MA-PPO trainer of the reference (train/policy/multi_ppo.py), batched over E x N.
+
+Same constructor arguments, same method names (`training_loop`, `update`,
+`compute_loss_pi`, `compute_loss_v`, `save_model`) and the same checkpoint layout
+(`model_state`, `pi_optimizer`, `vf_optimizer`, multi_ppo.py:411-412).  What changes
+is the shape of the data: the reference keeps one python buffer per drone and steps
+one env; here a rollout is `[T, E, N, ...]` tensors on the GPU, produced by
+`BatchedDroneEnv.step_policy` (the env step, the trainer's action glue and the
+reset protocol in one HIP launch per step).
+
+Path-cut rules of the reference (multi_ppo.py:226-281), per env:
+  * a collision resets the collided drone and does NOT end the path;
+  * when any drone finishes or exceeds max_ep_len, or the epoch ends, the path of
+    EVERY drone of that env ends with bootstrap value 0 (`finish_path(0)` sits
+    outside the `if`, :279);
+  * advantages are not normalised.
+GAE follows multi_PPObuf.finish_path (:68-77) in float64 (np.append promotes the
+float32 buffers) and is stored as float32.
+
+Multi-GPU: envs are sharded one process per GPU; the only
+collectives are one all-reduce of the flattened gradient bucket per optimizer step
+and the mean of the KL estimate (so every rank leaves the policy loop together).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+from torch.optim import Adam
+
+
+def gae_scan(rew, val, cut, gamma=0.99, lam=0.97):
+    """Reverse scan over time.  rew, val: float [T, ...]; cut: bool [T, ...], True where
+    the path ends after step t (bootstrap 0).  Returns (adv, ret) float32.
+
+    multi_PPObuf.finish_path (multi_ppo.py:68-77) per path:
+        deltas = r_t + gamma * V_{t+1} - V_t,  V_end = 0
+        adv    = discount_cumsum(deltas, gamma * lam)
+        ret    = discount_cumsum(rews + [0], gamma)[:-1]
+    """
+    T = rew.shape[0]
+    r, v = rew.to(torch.float64), val.to(torch.float64)
+    keep = (~cut.to(torch.bool)).to(torch.float64)
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    nxt_v = torch.zeros_like(r[0])
+    nxt_a = torch.zeros_like(r[0])
+    nxt_r = torch.zeros_like(r[0])
+    for t in range(T - 1, -1, -1):
+        k = keep[t]
+        delta = r[t] + gamma * (k * nxt_v) - v[t]
+        nxt_a = delta + (gamma * lam) * (k * nxt_a)
+        nxt_r = r[t] + gamma * (k * nxt_r)
+        adv[t], ret[t] = nxt_a, nxt_r
+        nxt_v = v[t]
+    return adv.to(torch.float32), ret.to(torch.float32)
+
+
+class RolloutBuffer:
+    """[T, E, N, ...] storage on the device (the batched multi_PPObuf, multi_ppo.py:39-94)."""
+
+    def __init__(self, T, E, N, obs_width, act_dim, device, gamma=0.99, lam=0.95):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.obs = torch.zeros((T, E, N, obs_width), **f32)
+        self.cnt = torch.zeros((T, E, N), dtype=torch.int32, device=device)
+        self.act = torch.zeros((T, E, N, act_dim), **f32)
+        self.rew = torch.zeros((T, E, N), **f32)
+        self.val = torch.zeros((T, E, N), **f32)
+        self.logp = torch.zeros((T, E, N), **f32)
+        self.cut = torch.zeros((T, E), dtype=torch.bool, device=device)
+        self.gamma, self.lam, self.ptr, self.T = gamma, lam, 0, T
+
+    def store(self, obs, cnt, act, rew, val, logp):
+        assert self.ptr < self.T  # multi_ppo.py:59
+        t = self.ptr
+        self.obs[t].copy_(obs); self.cnt[t].copy_(cnt); self.act[t].copy_(act)
+        self.rew[t].copy_(rew); self.val[t].copy_(val); self.logp[t].copy_(logp)
+        self.ptr += 1
+
+    def finish_path(self, env_mask):
+        """finish_path(0) for every drone of the masked envs at the last stored step."""
+        self.cut[self.ptr - 1] |= env_mask
+
+    def get(self):
+        assert self.ptr == self.T  # buffer has to be full (multi_ppo.py:80)
+        cut = self.cut.unsqueeze(-1).expand_as(self.rew)
+        adv, ret = gae_scan(self.rew, self.val, cut, self.gamma, self.lam)
+        self.ptr = 0
+        self.cut.zero_()
+        flat = lambda x: x.reshape((-1,) + x.shape[3:])
+        return dict(obs=flat(self.obs), cnt=flat(self.cnt), act=flat(self.act), ret=flat(ret),
+                    adv=flat(adv), logp=flat(self.logp))
+
+
+class multi_ppo:
+    def __init__(self, env, ac_policy, pi_lr=3e-4, vf_lr=1e-3, train_epoch=50,
+                 steps_per_epoch=600, max_ep_len=300, gamma=0.99, lam=0.97, clip_ratio=0.2,
+                 train_pi_iters=100, train_v_iters=100, target_kl=0.01, render=False,
+                 render_freq=20, con_train=False, seed=7, save_freq=50, save_figure=False,
+                 save_path="test/", save_name="test", load_fname=None, use_gpu=True,
+                 save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
+                 max_update_num=10, mpi=False, figure_save_path=None, minibatch_size=None,
+                 dist=None, **kwargs):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        self.env, self.ac, self.dist = env, ac_policy, dist
+        self.E, self.N = env.E, env.N
+        self.robot_num = env.N  # env.ir_gym.drone_num (multi_ppo.py:110)
+        self.device = env.device
+        # the shared reader sits in both optimizers, as in the reference (multi_ppo.py:115-116)
+        pi_params = self.ac.pi.parameters() if hasattr(self.ac.pi, "parameters") else \
+            list(self.ac.pi_net.parameters()) + [self.ac.log_std]
+        v_params = self.ac.v.parameters() if hasattr(self.ac.v, "parameters") else \
+            self.ac.v_net.parameters()
+        self.pi_optimizer = Adam(pi_params, lr=pi_lr)
+        self.vf_optimizer = Adam(v_params, lr=vf_lr)
+        if con_train and load_fname:  # resume loads the weights only (multi_ppo.py:118-121)
+            ck = torch.load(load_fname, map_location=self.device, weights_only=True)
+            self.ac.load_state_dict(ck["model_state"], strict=True)
+            self.ac.train()
+        self.epoch, self.max_ep_len, self.steps_per_epoch = train_epoch, max_ep_len, steps_per_epoch
+        self.clip_ratio, self.train_pi_iters = clip_ratio, train_pi_iters
+        self.train_v_iters, self.target_kl = train_v_iters, target_kl
+        self.save_freq, self.save_path, self.save_name = save_freq, save_path, save_name
+        self.use_gpu, self.minibatch_size = use_gpu, minibatch_size
+        self.buf = RolloutBuffer(steps_per_epoch, self.E, self.N, env.W, 3, self.device, gamma, lam)
+        self.ep_len = torch.zeros((self.E, self.N), dtype=torch.int32, device=self.device)
+        self.ep_ret = torch.zeros((self.E, self.N), dtype=torch.float32, device=self.device)
+        self.log = []
+
+    # ---- rollout ------------------------------------------------------------------------
+    def collect(self):
+        """One epoch of steps_per_epoch env steps (multi_ppo.py:183-281), on the device."""
+        env, buf = self.env, self.buf
+        obs, cnt = env.obs, env.vo_count
+        ret_sum = torch.zeros((), device=self.device)
+        ret_n = torch.zeros((), device=self.device)
+        for t in range(self.steps_per_epoch):
+            a, v, logp = self.ac.step_tensors((obs.view(-1, env.W), cnt.view(-1)))
+            a = a.view(self.E, self.N, 3)
+            prev_obs, prev_cnt = obs.clone(), cnt.clone()
+            # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
+            # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
+            obs, cnt, rew, done, info, fin = env.step_policy(a, autoreset=True)
+            a_inc = torch.round(a * 100.0) / 100.0  # what the reference stores (multi_ppo.py:197)
+            buf.store(prev_obs, prev_cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))
+            self.ep_ret += torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+            self.ep_len += 1
+            finb, doneb = fin.bool(), done.bool()
+            timeout = self.ep_len > self.max_ep_len
+            epoch_ended = t == self.steps_per_epoch - 1
+            terminal = (finb | timeout).any(dim=1)  # any drone of the env (multi_ppo.py:229)
+            ended = doneb | finb | timeout
+            ret_sum += (self.ep_ret * ended).sum()
+            ret_n += ended.sum()
+            extra = timeout & ~(doneb | finb)  # not yet reset by the fused step
+            if epoch_ended:
+                extra = ~(doneb | finb)         # full reset (multi_ppo.py:244-264)
+                terminal = torch.ones_like(terminal)
+                ended = torch.ones_like(ended)
+            if epoch_ended or bool(extra.any()):
+                env.reset_drones(extra)
+                obs, cnt = env.observe()
+            buf.finish_path(terminal)
+            self.ep_ret = torch.where(ended, torch.zeros_like(self.ep_ret), self.ep_ret)
+            self.ep_len = torch.where(ended, torch.zeros_like(self.ep_len), self.ep_len)
+        return float(ret_sum / ret_n.clamp(min=1))
+
+    def training_loop(self):
+        self.env.reset()
+        self.env.observe()
+        for epoch in range(self.epoch + 1):
+            t0 = time.time()
+            mean_ret = self.collect()
+            if (epoch % self.save_freq == 0) or (epoch == self.epoch):
+                self.save_model(epoch)
+            data = self.buf.get()
+            stats = self.update(data)
+            self.log.append(dict(epoch=epoch, mean_return=mean_ret, seconds=time.time() - t0, **stats))
+        return self.log
+
+    # ---- update -------------------------------------------------------------------------
+    def _allreduce_grads(self):
+        d = self.dist
+        if d is None or not d.is_initialized() or d.get_world_size() == 1:
+            return
+        grads = [p.grad for p in self.ac.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        d.all_reduce(flat)  # one bucket per optimizer step (0.7 - 2.7 MB: latency-bound on xGMI)
+        flat /= d.get_world_size()
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
+    def _mean_over_ranks(self, x: float) -> float:
+        d = self.dist
+        if d is None or not d.is_initialized() or d.get_world_size() == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.device)
+        d.all_reduce(t)
+        return float(t.item()) / d.get_world_size()
+
+    def _batches(self, n):
+        mb = self.minibatch_size or n
+        if mb >= n:
+            yield slice(None)
+        else:
+            perm = torch.randperm(n, device=self.device)
+            for i in range(0, n, mb):
+                yield perm[i:i + mb]
+
+    def update(self, data):
+        n = data["adv"].shape[0]
+        kl, pi_steps = 0.0, 0
+        for i in range(self.train_pi_iters):  # multi_ppo.py:355-368
+            stop = False
+            for idx in self._batches(n):
+                mb = {k: v[idx] for k, v in data.items()}
+                self.pi_optimizer.zero_grad()
+                loss_pi, pi_info = self.compute_loss_pi(mb)
+                kl = self._mean_over_ranks(pi_info["kl"])
+                if kl > self.target_kl:  # KL check before the step
+                    stop = True
+                    break
+                loss_pi.backward()
+                self._allreduce_grads()
+                torch.nn.utils.clip_grad_norm_(self.ac.parameters(), max_norm=2.0)
+                self.pi_optimizer.step()
+                pi_steps += 1
+            if stop:
+                break
+        loss_v = torch.zeros(())
+        for i in range(self.train_v_iters):  # multi_ppo.py:371-376
+            for idx in self._batches(n):
+                mb = {k: v[idx] for k, v in data.items()}
+                self.vf_optimizer.zero_grad()
+                loss_v = self.compute_loss_v(mb)
+                loss_v.backward()
+                self._allreduce_grads()
+                self.vf_optimizer.step()
+        return dict(kl=kl, pi_steps=pi_steps, loss_v=float(loss_v))
+
+    def _obs_arg(self, data):
+        return (data["obs"], data["cnt"]) if "cnt" in data else data["obs"]
+
+    def compute_loss_v(self, data):  # multi_ppo.py:379-383
+        return ((self.ac.v(self._obs_arg(data)) - data["ret"]) ** 2).mean()
+
+    def compute_loss_pi(self, data):  # multi_ppo.py:385-404
+        act, adv, logp_old = data["act"], data["adv"], data["logp"]
+        pi, logp = self.ac.pi(self._obs_arg(data), act)
+        ratio = torch.exp(logp - logp_old)
+        clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv
+        loss_pi = -(torch.min(ratio * adv, clip_adv)).mean()
+        approx_kl = (logp_old - logp).mean().item()
+        ent = pi.entropy().mean().item()
+        clipped = ratio.gt(1 + self.clip_ratio) | ratio.lt(1 - self.clip_ratio)
+        clipfrac = clipped.float().mean().item()
+        return loss_pi, dict(kl=approx_kl, ent=ent, cf=clipfrac)
+
+    def save_model(self, index=0):  # multi_ppo.py:406-420
+        os.makedirs(self.save_path, exist_ok=True)
+        state = dict(model_state=self.ac.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
+                     vf_optimizer=self.vf_optimizer.state_dict())
+        torch.save(self.ac, os.path.join(self.save_path, f"{self.save_name}_{index}.pt"))
+        torch.save(state, os.path.join(self.save_path, f"{self.save_name}_check_point_{index}.pt"))

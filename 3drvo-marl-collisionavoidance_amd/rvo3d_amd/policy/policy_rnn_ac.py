@@ -1,0 +1,258 @@
+"""Actor-critic of the reference (train/policy/policy_rnn_ac.py), batched.
+
+Same constructor, same sub-module names - so a reference checkpoint's
+`model_state` loads with strict=True - same methods (`step`, `act`, `pi(obs, act)`,
+`v(obs)`), plus a batched calling convention used by the rollout engine:
+
+    obs   : float32 [B, 12 + 9*nm]   padded rows as the env emits them
+    count : int32   [B]              valid VO rows (0 = the single all-zero row)
+
+The reference feeds a ragged list through pad_sequence / pack_padded_sequence
+(policy_rnn_ac.py:129-168), which needs the lengths on the host.  Here the biGRU is
+unrolled over the nm slots with a validity mask (forward direction: steps 0..len-1;
+reverse direction: steps len-1..0), which is the same function of the valid rows and
+never synchronises with the host; every step is a [B, 9]x[9, 3H] + [B, H]x[H, 3H] GEMM.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions.normal import Normal
+
+
+def mlp(sizes, activation, output_activation=nn.Identity):  # policy_rnn_ac.py:10-17
+    layers = []
+    for j in range(len(sizes) - 1):
+        act = activation if j < len(sizes) - 2 else output_activation
+        layers += [nn.Linear(sizes[j], sizes[j + 1]), act()]
+    return nn.Sequential(*layers)
+
+
+def _as_batch(obs, state_dim, input_dim, device=None):
+    """Accept (obs[B,W], count[B]) | list of ragged 1-D tensors | one ragged 1-D tensor.
+    Returns (padded [B, W], lengths [B] >= 1, was_single)."""
+    if isinstance(obs, tuple):
+        o, c = obs
+        return o, torch.clamp(c.to(torch.int64), min=1), False
+    single = not isinstance(obs, (list, tuple))
+    items = [obs] if single else list(obs)
+    items = [torch.as_tensor(x, dtype=torch.float32) for x in items]
+    lens = torch.tensor([max((len(x) - state_dim) // input_dim, 1) for x in items])
+    W = state_dim + input_dim * int(lens.max())
+    out = torch.zeros((len(items), W), dtype=torch.float32)
+    for i, x in enumerate(items):
+        out[i, :len(x)] = x
+    if device is not None:
+        out, lens = out.to(device), lens.to(device)
+    return out, lens, single
+
+
+class rnn_Reader(nn.Module):  # policy_rnn_ac.py:75-168
+    def __init__(self, state_dim, input_dim, hidden_dim, use_gpu=False, mode="GRU"):
+        super().__init__()
+        self.state_dim, self.input_dim, self.hidden_dim = state_dim, input_dim, hidden_dim
+        self.mode, self.use_gpu = mode, use_gpu
+        if mode == "GRU":
+            self.rnn_net = nn.GRU(input_dim, hidden_dim, batch_first=True)
+        elif mode == "LSTM":
+            self.rnn_net = nn.LSTM(input_dim, hidden_dim, batch_first=True)
+        elif mode == "biGRU":
+            self.rnn_net = nn.GRU(input_dim, hidden_dim, batch_first=True, bidirectional=True)
+        else:
+            raise ValueError(mode)
+        self.ln = nn.LayerNorm(state_dim + hidden_dim)
+        if use_gpu:
+            self.rnn_net, self.ln = self.rnn_net.cuda(), self.ln.cuda()
+
+    def _gru_dir(self, x, lens, suffix, reverse):
+        """Final hidden state of one GRU direction over the valid prefix of each row."""
+        r = self.rnn_net
+        w_ih, w_hh = getattr(r, "weight_ih_l0" + suffix), getattr(r, "weight_hh_l0" + suffix)
+        b_ih, b_hh = getattr(r, "bias_ih_l0" + suffix), getattr(r, "bias_hh_l0" + suffix)
+        B, S, _ = x.shape
+        H = self.hidden_dim
+        gi_all = torch.addmm(b_ih, x.reshape(B * S, -1), w_ih.t()).view(B, S, 3 * H)
+        h = x.new_zeros((B, H))
+        steps = range(S - 1, -1, -1) if reverse else range(S)
+        for t in steps:
+            gh = torch.addmm(b_hh, h, w_hh.t())
+            gi = gi_all[:, t]
+            i_r, i_z, i_n = gi.chunk(3, 1)
+            h_r, h_z, h_n = gh.chunk(3, 1)
+            rg = torch.sigmoid(i_r + h_r)
+            zg = torch.sigmoid(i_z + h_z)
+            ng = torch.tanh(i_n + rg * h_n)
+            hn = (1 - zg) * ng + zg * h
+            h = torch.where((lens > t).unsqueeze(1), hn, h)
+        return h
+
+    def forward_batch(self, obs, lens):
+        """obs [B, state_dim + input_dim*S] padded; lens [B] >= 1."""
+        B = obs.shape[0]
+        robot = obs[:, :self.state_dim]
+        S = (obs.shape[1] - self.state_dim) // self.input_dim
+        x = obs[:, self.state_dim:self.state_dim + S * self.input_dim].reshape(B, S, self.input_dim)
+        lens = lens.to(obs.device)
+        if self.mode == "LSTM":
+            packed = nn.utils.rnn.pack_padded_sequence(x, lens.cpu(), batch_first=True,
+                                                       enforce_sorted=False)
+            _, (hn, _) = self.rnn_net(packed)
+            hnv = hn[0]
+        else:
+            hnv = self._gru_dir(x, lens, "", False)
+            if self.mode == "biGRU":  # sum of the two directions (policy_rnn_ac.py:121-122)
+                hnv = hnv + self._gru_dir(x, lens, "_reverse", True)
+        return self.ln(torch.cat((robot, hnv), 1))
+
+    # reference names
+    def obs_rnn(self, obs):
+        o, lens, _ = _as_batch(obs, self.state_dim, self.input_dim, self._device())
+        return self.forward_batch(o, lens)[0]
+
+    def obs_rnn_list(self, obs_tensor_list):
+        o, lens, _ = _as_batch(list(obs_tensor_list), self.state_dim, self.input_dim, self._device())
+        return self.forward_batch(o, lens)
+
+    def _device(self):
+        return self.ln.weight.device
+
+
+class Actor(nn.Module):  # policy_rnn_ac.py:170-188
+    def forward(self, obs, act=None, std_factor=1):
+        pi = self._distribution(obs, std_factor)
+        logp_a = None
+        if act is not None:
+            logp_a = self._log_prob_from_distribution(pi, act)
+        return pi, logp_a
+
+
+class GaussianActor(Actor):  # policy_rnn_ac.py:191-235
+    def __init__(self, obs_dim, act_dim, hidden_sizes, activation, output_activation,
+                 rnn_reader=None, use_gpu=False):
+        super().__init__()
+        self.rnn_reader, self.use_gpu = rnn_reader, use_gpu
+        self.net_out = mlp([obs_dim] + list(hidden_sizes) + [act_dim], activation, output_activation)
+        log_std = -1 * np.ones(act_dim, dtype=np.float32)
+        self.log_std = torch.nn.Parameter(torch.as_tensor(log_std))
+        if use_gpu:
+            self.net_out = self.net_out.cuda()
+            self.log_std = torch.nn.Parameter(torch.as_tensor(log_std, device=torch.device("cuda")))
+
+    def _features(self, obs):
+        r = self.rnn_reader
+        o, lens, single = _as_batch(obs, r.state_dim, r.input_dim, r._device())
+        return r.forward_batch(o, lens), single
+
+    def _distribution(self, obs, std_factor=1, check=False):
+        feat, single = self._features(obs)
+        if check and not torch.isfinite(feat).all():  # policy_rnn_ac.py:214-216 (host sync)
+            raise ValueError("observation contains NaN/Inf")
+        mu = self.net_out(feat)
+        std = torch.clamp(std_factor * torch.exp(self.log_std) + 1e-6, min=1e-4, max=10.0)
+        if single:
+            mu = mu[0]
+        return Normal(mu, std)
+
+    def _log_prob_from_distribution(self, pi, act):
+        return pi.log_prob(act.to(pi.mean.device)).sum(axis=-1)
+
+
+class Critic(nn.Module):  # policy_rnn_ac.py:238-257
+    def __init__(self, obs_dim, hidden_sizes, activation, output_activation, rnn_reader=None,
+                 use_gpu=False):
+        super().__init__()
+        self.v_net = mlp([obs_dim] + list(hidden_sizes) + [1], activation, output_activation)
+        if use_gpu:
+            self.v_net = self.v_net.cuda()
+        self.rnn_reader = rnn_reader
+
+    def forward(self, obs):
+        r = self.rnn_reader
+        o, lens, single = _as_batch(obs, r.state_dim, r.input_dim, r._device())
+        v = torch.squeeze(self.v_net(r.forward_batch(o, lens)), -1)
+        return v[0] if single else v
+
+
+class rnn_ac(nn.Module):  # policy_rnn_ac.py:31-72
+    def __init__(self, observation_space, action_space, state_dim, rnn_input_dim=9,
+                 rnn_hidden_dim=64, hidden_sizes_ac=(256, 256), hidden_sizes_v=(16, 16),
+                 activation=nn.ReLU, output_activation=nn.Tanh, output_activation_v=nn.Identity,
+                 use_gpu=True, rnn_mode="GRU", drop_p=0):
+        super().__init__()
+        self.use_gpu = use_gpu
+        obs_dim = rnn_hidden_dim + state_dim
+        rnn = rnn_Reader(state_dim, rnn_input_dim, rnn_hidden_dim, use_gpu=use_gpu, mode=rnn_mode)
+        act_dim = action_space.shape[0] if hasattr(action_space, "shape") else int(action_space)
+        self.pi = GaussianActor(obs_dim, act_dim, hidden_sizes_ac, activation, output_activation,
+                                rnn_reader=rnn, use_gpu=use_gpu)
+        self.v = Critic(obs_dim, hidden_sizes_v, activation, output_activation_v, rnn_reader=rnn,
+                        use_gpu=use_gpu)
+
+    def step_tensors(self, obs, std_factor=1):
+        """Batched, stays on the device: (a, v, logp) tensors."""
+        with torch.no_grad():
+            pi_dis = self.pi._distribution(obs, std_factor)
+            a = pi_dis.sample()
+            logp_a = self.pi._log_prob_from_distribution(pi_dis, a)
+            v = self.v(obs)
+        return a, v, logp_a
+
+    def step(self, obs, std_factor=1):  # reference: numpy out (policy_rnn_ac.py:57-69)
+        a, v, logp_a = self.step_tensors(obs, std_factor)
+        return a.cpu().numpy(), v.cpu().numpy(), logp_a.cpu().numpy()
+
+    def act(self, obs, std_factor=1):
+        return self.step(obs, std_factor)[0]
+
+
+class _NoReader(nn.Module):
+    """Reader of the MLP policy: the padded observation itself (no recurrence)."""
+
+    def __init__(self, width):
+        super().__init__()
+        self.state_dim, self.input_dim, self.width = width, 1, width
+
+    def forward_batch(self, obs, lens):
+        return obs
+
+    def _device(self):
+        return next(self.parameters(), torch.zeros(())).device
+
+
+class mlp_ac(nn.Module):
+    """BASELINE config 3's MLP(256, 256) actor-critic on the fixed-width padded
+    observation (12 + 9*nm floats): same `pi` / `v` / `step` surface as rnn_ac."""
+
+    def __init__(self, obs_width, act_dim=3, hidden_sizes=(256, 256), activation=nn.ReLU,
+                 output_activation=nn.Tanh):
+        super().__init__()
+        self.obs_width = obs_width
+        self.pi_net = mlp([obs_width] + list(hidden_sizes) + [act_dim], activation, output_activation)
+        self.v_net = mlp([obs_width] + list(hidden_sizes) + [1], activation, nn.Identity)
+        self.log_std = nn.Parameter(-1 * torch.ones(act_dim))
+
+    def _obs(self, obs):
+        return obs[0] if isinstance(obs, tuple) else obs
+
+    def dist(self, obs, std_factor=1):
+        mu = self.pi_net(self._obs(obs))
+        std = torch.clamp(std_factor * torch.exp(self.log_std) + 1e-6, min=1e-4, max=10.0)
+        return Normal(mu, std)
+
+    def pi(self, obs, act=None, std_factor=1):
+        d = self.dist(obs, std_factor)
+        return d, (None if act is None else d.log_prob(act).sum(-1))
+
+    def v(self, obs):
+        return self.v_net(self._obs(obs)).squeeze(-1)
+
+    def step_tensors(self, obs, std_factor=1):
+        with torch.no_grad():
+            d = self.dist(obs, std_factor)
+            a = d.sample()
+            return a, self.v(obs), d.log_prob(a).sum(-1)
+
+    def step(self, obs, std_factor=1):
+        a, v, lp = self.step_tensors(obs, std_factor)
+        return a.cpu().numpy(), v.cpu().numpy(), lp.cpu().numpy()

@@ -300,3 +300,26 @@ def test_step_policy_trainer_glue():
     np.testing.assert_allclose(s["pos"].cpu().numpy()[ok_env], rs["pos"][ok_env], rtol=1e-9, atol=1e-9)
     assert rows > 0
     env.close()
+
+
+@pytest.mark.parametrize("kind", ["mlp", "rnn"])
+def test_training_loop_end_to_end(kind, tmp_path):
+    """8(f) rows 1-2 on the device: rollout through rvo3d_step_policy, batched GAE with the
+    reference's path-cut rules, clipped-PPO update; checkpoint layout of the reference."""
+    from rvo3d_amd.policy import mlp_ac, multi_ppo, rnn_ac
+    env = BatchedDroneEnv(synthetic_world(64, 8, (20, 20, 8), n_points=3, seed=4))
+
+    class Space:
+        shape = (3,)
+    ac = (mlp_ac(env.W) if kind == "mlp" else
+          rnn_ac(None, Space(), 12, 9, 64, (64, 64), (64, 64), torch.nn.ReLU, torch.nn.Tanh,
+                 torch.nn.Identity, use_gpu=False, rnn_mode="biGRU")).cuda()
+    tr = multi_ppo(env, ac, pi_lr=3e-4, vf_lr=1e-3, train_epoch=1, steps_per_epoch=24,
+                   max_ep_len=15, train_pi_iters=4, train_v_iters=4, target_kl=0.05,
+                   save_path=str(tmp_path) + "/", save_name="t", save_freq=1)
+    log = tr.training_loop()
+    assert len(log) == 2 and all(np.isfinite(l["loss_v"]) for l in log)
+    ck = torch.load(str(tmp_path / "t_check_point_1.pt"), weights_only=True)
+    assert set(ck) == {"model_state", "pi_optimizer", "vf_optimizer"}   # multi_ppo.py:411-412
+    assert env.error_flags() == 0
+    env.close()

@@ -1,0 +1,185 @@
+"""Policy / PPO surface against vectors produced by the
+reference's own classes on CPU (oracle/gen_golden_policy.py): rnn_ac forward,
+multi_PPObuf GAE, compute_loss_pi / compute_loss_v incl. gradients.  CPU only."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from golden_util import GOLDEN, load
+from rvo3d_amd.policy import gae_scan, mlp_ac, multi_ppo, rnn_ac
+from rvo3d_amd.policy.multi_ppo import RolloutBuffer
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+class _Space:
+    shape = (3,)
+
+
+def small_ac(fx):
+    ac = rnn_ac(None, _Space(), 12, 9, 32, (32, 32), (32, 32), torch.nn.ReLU, torch.nn.Tanh,
+                torch.nn.Identity, use_gpu=False, rnn_mode="biGRU")
+    sd = {k[2:]: torch.as_tensor(v) for k, v in fx.items() if k.startswith("w:")}
+    ac.load_state_dict(sd, strict=True)  # same key names as the reference module
+    return ac.eval()
+
+
+def ragged(fx):
+    out = []
+    for o, c in zip(fx["obs"], fx["count"]):
+        out.append(torch.as_tensor(o[:12 + 9 * max(int(c), 1)]))
+    return out
+
+
+def test_checkpoint_key_names_and_shapes():
+    """A reference checkpoint (`model_state`, biGRU 256 / MLP 256-256) loads strict."""
+    ac = rnn_ac(None, _Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh,
+                torch.nn.Identity, use_gpu=False, rnn_mode="biGRU")
+    want = {}
+    for line in open(os.path.join(GOLDEN, "policy_rnn_ac_keys.txt")):
+        k, shp = line.split(" ", 1)
+        want[k] = eval(shp)
+    have = {k: tuple(v.shape) for k, v in ac.state_dict().items()}
+    assert have == want
+    assert sum(p.numel() for p in ac.parameters()) == 680991
+
+
+def test_rnn_ac_forward_matches_reference():
+    fx = load(os.path.join(GOLDEN, "policy_rnn_ac.npz"))
+    ac = small_ac(fx)
+    obs = torch.as_tensor(fx["obs"])
+    cnt = torch.as_tensor(fx["count"])
+    act = torch.as_tensor(fx["act"])
+    with torch.no_grad():
+        pi, logp = ac.pi((obs, cnt), act)            # batched padded path (masked biGRU)
+        v = ac.v((obs, cnt))
+        pil, logpl = ac.pi(ragged(fx), act)          # the reference's list-of-ragged path
+        pis, _ = ac.pi((obs, cnt), act, std_factor=1e-3)
+    for got, key in ((pi.mean, "mu"), (pi.stddev.expand_as(pi.mean), "std"), (logp, "logp"),
+                     (v, "v"), (pil.mean, "mu"), (logpl, "logp"), (pi.entropy(), "entropy"),
+                     (pis.stddev.expand_as(pi.mean), "std_small")):
+        np.testing.assert_allclose(got.numpy(), fx[key], **TOL, err_msg=key)
+    with torch.no_grad():  # single ragged observation, as ac.step(obs) in the trainer
+        for i in range(8):
+            o = ragged(fx)[i]
+            np.testing.assert_allclose(ac.pi._distribution(o).mean.numpy(), fx["single_mu"][i], **TOL)
+            np.testing.assert_allclose(float(ac.v(o)), fx["single_v"][i], **TOL)
+    a, vv, lp = ac.step(ragged(fx)[2])
+    assert a.shape == (3,) and vv.shape == () and lp.shape == ()
+
+
+def test_gae_matches_multi_PPObuf():
+    fx = load(os.path.join(GOLDEN, "ppo_gae.npz"))
+    rew, val, cut = (torch.as_tensor(fx[k]) for k in ("rew", "val", "cuts"))
+    adv, ret = gae_scan(rew, val, cut.bool(), float(fx["gamma"]), float(fx["lam"]))
+    np.testing.assert_allclose(adv.numpy(), fx["adv"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ret.numpy(), fx["ret"], rtol=1e-5, atol=1e-6)
+    # batched [T, E, N] layout with per-env cuts == the same scan per column
+    T = rew.shape[0]
+    R = rew[:, None, None].expand(T, 3, 2).contiguous()
+    V = val[:, None, None].expand(T, 3, 2).contiguous()
+    C = cut.bool()[:, None, None].expand(T, 3, 2)
+    A2, R2 = gae_scan(R, V, C, 0.99, 0.97)
+    np.testing.assert_array_equal(A2[:, 1, 1].numpy(), adv.numpy())
+    np.testing.assert_array_equal(R2[:, 2, 0].numpy(), ret.numpy())
+
+
+def test_rollout_buffer_cut_rules():
+    buf = RolloutBuffer(4, 2, 3, 21, 3, "cpu", 0.99, 0.97)
+    for t in range(4):
+        buf.store(torch.zeros(2, 3, 21), torch.zeros(2, 3, dtype=torch.int32), torch.zeros(2, 3, 3),
+                  torch.ones(2, 3), torch.zeros(2, 3), torch.zeros(2, 3))
+        buf.finish_path(torch.tensor([t == 1, False]) | torch.tensor([t == 3, t == 3]))
+    with pytest.raises(AssertionError):
+        buf.store(*[None] * 6)
+    d = buf.get()
+    ret = d["ret"].view(4, 2, 3)
+    np.testing.assert_allclose(ret[:, 0, 0].numpy(), [1.99, 1.0, 1.99, 1.0], rtol=1e-6)  # cut after t=1
+    np.testing.assert_allclose(ret[:, 1, 2].numpy(), [1 + .99 * (1 + .99 * 1.99), 1 + .99 * 1.99, 1.99, 1.0], rtol=1e-6)
+    assert d["obs"].shape == (24, 21) and buf.ptr == 0
+
+
+class _FakeEnv:
+    E, N, W, device = 1, 1, 102, torch.device("cpu")
+
+
+def test_losses_and_gradients_match_reference():
+    fx = load(os.path.join(GOLDEN, "policy_rnn_ac.npz"))
+    lx = load(os.path.join(GOLDEN, "ppo_loss.npz"))
+    ac = small_ac(fx)
+    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, use_gpu=False)
+    data = dict(obs=torch.as_tensor(fx["obs"]), cnt=torch.as_tensor(fx["count"]),
+                act=torch.as_tensor(fx["act"]), adv=torch.as_tensor(lx["adv"]),
+                ret=torch.as_tensor(lx["ret"]), logp=torch.as_tensor(lx["logp_old"]))
+    ac.zero_grad()
+    loss_pi, info = tr.compute_loss_pi(data)
+    loss_pi.backward()
+    assert abs(float(loss_pi) - float(lx["loss_pi"])) < 1e-5
+    for k in ("kl", "ent", "cf"):
+        assert abs(info[k] - float(lx[k])) < 1e-5, k
+    g = dict(ac.named_parameters())
+    np.testing.assert_allclose(g["pi.log_std"].grad.numpy(), lx["g_pi_log_std"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g["pi.net_out.4.weight"].grad.numpy(), lx["g_pi_out"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(g["pi.rnn_reader.rnn_net.weight_ih_l0"].grad.numpy(), lx["g_pi_gru"],
+                               rtol=1e-3, atol=1e-6)
+    ac.zero_grad()
+    loss_v = tr.compute_loss_v(data)
+    loss_v.backward()
+    assert abs(float(loss_v) - float(lx["loss_v"])) < 1e-4 * max(1.0, abs(float(lx["loss_v"])))
+    np.testing.assert_allclose(g["v.v_net.4.weight"].grad.numpy(), lx["g_v_out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g["pi.rnn_reader.rnn_net.weight_hh_l0_reverse"].grad.numpy(), lx["g_v_gru"],
+                               rtol=1e-3, atol=1e-6)
+
+
+def test_mlp_ac_surface():
+    ac = mlp_ac(102)
+    obs = torch.randn(5, 102)
+    a, v, lp = ac.step_tensors((obs, torch.zeros(5, dtype=torch.int32)))
+    assert a.shape == (5, 3) and v.shape == (5,) and lp.shape == (5,)
+    d, logp = ac.pi(obs, a)
+    assert torch.allclose(logp, lp, atol=1e-6)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    ac = mlp_ac(21, hidden_sizes=(16, 16))
+    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, train_pi_iters=3, train_v_iters=2,
+                   target_kl=1e9, use_gpu=False, dist=dist, seed=0)
+    g = torch.Generator().manual_seed(100 + rank)  # every rank has its own shard of samples
+    n = 64
+    data = dict(obs=torch.randn(n, 21, generator=g), act=torch.randn(n, 3, generator=g) * 0.3,
+                adv=torch.randn(n, generator=g), ret=torch.randn(n, generator=g),
+                logp=torch.randn(n, generator=g) * 0.1 - 2.0)
+    tr.update(data)
+    q.put((rank, torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_keeps_ranks_identical():
+    """8(e): one all-reduce of the gradient bucket per optimizer step -> replicas stay equal."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_array_equal(out[0], out[1])
