@@ -101,7 +101,7 @@ class multi_ppo:
                  save_path="test/", save_name="test", load_fname=None, use_gpu=True,
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=10, mpi=False, figure_save_path=None, minibatch_size=None,
-                 dist=None, **kwargs):
+                 dist=None, sanitize_rewards=True, amp=False, **kwargs):
         torch.manual_seed(seed)
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
@@ -124,6 +124,13 @@ class multi_ppo:
         self.train_v_iters, self.target_kl = train_v_iters, target_kl
         self.save_freq, self.save_path, self.save_name = save_freq, save_path, save_name
         self.use_gpu, self.minibatch_size = use_gpu, minibatch_size
+        # The reference's RVO reward is inf / nan while a drone sits within 0.4 m of its
+        # waypoint (ir_gym.py:88, survey Q9) and would poison GAE; by default such rewards
+        # enter the buffer as 0 (set sanitize_rewards=False for the literal behaviour).
+        self.sanitize_rewards = sanitize_rewards
+        # amp=True runs the policy GEMMs of the rollout in bf16 (MFMA); the reference is fp32
+        self.amp = amp
+        self.nonfinite_rewards = 0
         self.buf = RolloutBuffer(steps_per_epoch, self.E, self.N, env.W, 3, self.device, gamma, lam)
         self.ep_len = torch.zeros((self.E, self.N), dtype=torch.int32, device=self.device)
         self.ep_ret = torch.zeros((self.E, self.N), dtype=torch.float32, device=self.device)
@@ -137,13 +144,17 @@ class multi_ppo:
         ret_sum = torch.zeros((), device=self.device)
         ret_n = torch.zeros((), device=self.device)
         for t in range(self.steps_per_epoch):
-            a, v, logp = self.ac.step_tensors((obs.view(-1, env.W), cnt.view(-1)))
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp):
+                a, v, logp = self.ac.step_tensors((obs.view(-1, env.W), cnt.view(-1)))
+            a, v, logp = a.float(), v.float(), logp.float()
             a = a.view(self.E, self.N, 3)
             prev_obs, prev_cnt = obs.clone(), cnt.clone()
             # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
             # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
             obs, cnt, rew, done, info, fin = env.step_policy(a, autoreset=True)
             a_inc = torch.round(a * 100.0) / 100.0  # what the reference stores (multi_ppo.py:197)
+            if self.sanitize_rewards:
+                rew = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
             buf.store(prev_obs, prev_cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))
             self.ep_ret += torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
             self.ep_len += 1
