@@ -49,9 +49,6 @@ struct rvo3d_env {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   bool world_loaded = false;
-  // the carry-over cache (dronestate + stage-G words) describes the current state:
-  // true after a step / observe launch, false after anything else wrote the state
-  bool cache_valid = false;
   int threads = 0, blocks = 0, lds = 0;
 };
 
@@ -77,8 +74,6 @@ int carve(rvo3d_env* h) {
       {(void**)&P.max_dev, EN * 8}, {(void**)&P.extra_len, EN * 8},
       {(void**)&P.wp_idx, EN * 4}, {(void**)&P.arrive, EN}, {(void**)&P.dest, EN},
       {(void**)&P.err, 256},
-      {(void**)&P.c_dvx, EN * 8}, {(void**)&P.c_dvy, EN * 8}, {(void**)&P.c_dvz, EN * 8},
-      {(void**)&P.c_dev, EN * 8}, {(void**)&P.c_cand, EN * 4 * 8},
       {(void**)&P.row_iet, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 8},
       {(void**)&P.row_pk, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 4},
   };
@@ -307,14 +302,12 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // the host staging vectors die here
   h->world_loaded = true;
-  h->cache_valid = false;
   return RVO3D_OK;
 }
 
 int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
-  h->cache_valid = false;
   const size_t EN = (size_t)h->P.E * h->P.N;
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), h->P, env_mask, (const uint8_t*)nullptr);
@@ -326,7 +319,6 @@ int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
   if (!drone_mask) return fail(RVO3D_ERR_INVALID, "drone_mask is required");
-  h->cache_valid = false;
   const size_t EN = (size_t)h->P.E * h->P.N;
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), h->P, (const uint8_t*)nullptr, drone_mask);
@@ -341,10 +333,7 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   Params P = h->P;
   P.obs = obs; P.vo_count = vo_count;
   P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
-  P.use_cache = 0;  // observe recomputes and refreshes the carry-over
-  rc = launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
-  h->cache_valid = (rc == RVO3D_OK) && P.ablate == 0 && !std::getenv("RVO3D_NO_CACHE");
-  return rc;
+  return launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
 }
 
 static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
@@ -362,10 +351,7 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  P.use_cache = h->cache_valid ? 1 : 0;
-  rc = autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
-  h->cache_valid = (rc == RVO3D_OK) && P.ablate == 0 && !std::getenv("RVO3D_NO_CACHE");
-  return rc;
+  return autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
 }
 
 int rvo3d_step(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
@@ -451,7 +437,6 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
                     const uint8_t* dest, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
-  h->cache_valid = false;
   const Params& P = h->P;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int EN = P.E * P.N;

@@ -80,12 +80,6 @@ struct Params {
   int32_t* wp_idx;
   uint8_t *arrive, *dest;
   uint32_t* err;
-  // Carry-over between consecutive steps (valid only while nothing but the step
-  // kernels touched the state; the host clears `use_cache` otherwise): dronestate of
-  // the state the last kernel left behind, and its stage-G candidate words.
-  double *c_dvx, *c_dvy, *c_dvz, *c_dev;  // [EN]
-  uint32_t* c_cand;                        // [EN][NW]
-  int use_cache;
   // kept VO rows of the sweep in flight, [nm][EN] each (touched only when a pair is flagged)
   double* row_iet;     // 1 / (t + 0.2), ascending urgency
   uint32_t* row_pk;    // (alpha * 100) << 16 | j
@@ -485,8 +479,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
 //   stage X2 (fp64, requested pairs only): pair_eval.
 // G and X1 only ever drop pairs that pair_eval would return "nothing" for.
 // NW = ceil(N / 64): words per request mask (64 drones) and per offset mask (32 offsets).
-// CC: 1 = take the stage-G words from the carry-over cache (when valid), 2 = leave them there
-template <int NW, bool ROWS, bool TOUCH, int CC = 0>
+template <int NW, bool ROWS, bool TOUCH>
 __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
                                          int g, bool active, const Drone& S, const double a[3],
                                          bool zero_act, bool& flag, double& tmin,
@@ -511,11 +504,8 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     valid_offsets<NW>(N, d, valid);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      uint32_t cand;
-      if (CC == 1 && P.use_cache) cand = P.c_cand[(size_t)g * NW + w];
-      else cand = far ? valid[w]
-                      : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
-      if (CC == 2) P.c_cand[(size_t)g * NW + w] = cand;
+      uint32_t cand = far ? valid[w]
+                          : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
       if (P.ablate & 64) cand = 0;
       while (cand) {  // stage X1: both directions of one candidate pair
         const int kb = __builtin_ctz(cand);
@@ -906,14 +896,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
         }
       }
     }
-    // drone.dronestate on the pre-move state (drone.py:254-263): the post-step dronestate
-    // of the previous launch when the state is untouched since (same inputs, same code)
-    if (P.use_cache) {
-      dv[0] = P.c_dvx[g]; dv[1] = P.c_dvy[g]; dv[2] = P.c_dvz[g]; dev = P.c_dev[g];
-    } else {
-      des_vel(P, p, cur, dv);
-      dev = deviation(prev, cur, p);
-    }
+    // drone.dronestate on the pre-move state (drone.py:254-263)
+    des_vel(P, p, cur, dv);
+    dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
   }
   RVO3D_STAMP(1);
@@ -935,13 +920,12 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   double tmin;
 
   if (MODE == kObserve) {
-    const int kept = sweep_env<NW, true, true, 2>(P, L, tid, el, d, g, active, S, zero3, true, flag,
+    const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision);
     if (active) {
       write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
       L.kept[tid] = kept;
       P.max_dev[g] = max_dev;
-      P.c_dvx[g] = dv[0]; P.c_dvy[g] = dv[1]; P.c_dvz[g] = dv[2]; P.c_dev[g] = dev;
     }
     __syncthreads();
     zero_fill(P, L, tid, e0 * N, nrows);
@@ -951,7 +935,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   RVO3D_STAMP(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   double rew_k = 0;
-  sweep_env<NW, false, false, 1>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
+  sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
                               tmin, collision);
   if (active) rew_k = rvo_reward_k(dv, a, flag, tmin);
   __syncthreads();  // everyone is done with the pre-move LDS image
@@ -1024,7 +1008,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   if (LITE) {
     if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
   } else {
-    kept = sweep_env<NW, true, true, 2>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
+    kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
                                      flag, tmin, collision);
   }
   if (active) {
@@ -1072,7 +1056,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       // rows for every env: ir_gym.observation_reward's VO part (env kept its state) or
       // ir_gym.env_observation with action 0 (env reset a drone, ir_gym.py:372-383)
       const double* aa = env_reset ? zero3 : az;
-      kept = sweep_env<NW, true, false, 2>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
+      kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
                                         env_reset, flag, tmin, c2);
       if (active) {
         if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
@@ -1100,7 +1084,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     P.max_dev[g] = max_dev; P.extra_len[g] = extra_len;
     P.wp_idx[g] = wpi;
     P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
-    P.c_dvx[g] = dv[0]; P.c_dvy[g] = dv[1]; P.c_dvz[g] = dv[2]; P.c_dev[g] = dev;
   }
   __syncthreads();  // L.kept complete
   RVO3D_STAMP(8);

@@ -138,10 +138,7 @@ int rvo3d_step_policy(rvo3d_env *h, const float *a_inc, float acceler, float *ob
 /* ir_gym.cal_des_list (ir_gym.py:44): desired velocity, des_vel [E][N][3] f64. */
 int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
 
-/* Zero-copy views of the state arrays.  Read freely.  The handle carries a small
- * cache from one step to the next (the post-step dronestate and candidate-pair words);
- * every entry point that changes the state drops it, a write through these raw views
- * cannot - after such a write call rvo3d_set_state (all-NULL arguments are enough). */
+/* Zero-copy views of the state arrays. */
 int rvo3d_state_ptrs(rvo3d_env *h, rvo3d_state_view *out);
 /* Array-of-structs copies: pos/vel [E][N][3] f64, the rest [E][N]; any
  * pointer may be NULL.  set_state is for tests and checkpoint restore. */
