@@ -46,6 +46,7 @@ double sq_threshold(double tau) {
 struct rvo3d_env {
   rvo3d_config cfg;
   Params P;             // pointers into `arena`
+  rvo3d::Cold cold;     // host copy of the rarely used parameters (device copy: P.cold_)
   void* arena = nullptr;
   size_t arena_bytes = 0;
   bool world_loaded = false;
@@ -58,24 +59,21 @@ namespace {
 int carve(rvo3d_env* h) {
   const rvo3d_config& c = h->cfg;
   const size_t EN = (size_t)c.num_envs * c.num_drones;
-  struct Field { void** slot; size_t bytes; };
+  const size_t S = align_up(EN, 64);  // common element stride of every per-drone array
   Params& P = h->P;
+  rvo3d::Cold& C = h->cold;
+  P.S = (uint32_t)S;
+  const size_t nf = Params::f64_arrays(c.max_points, c.neighbors_num);
+  const size_t ni = Params::i32_arrays(c.neighbors_num);
+  struct Field { void** slot; size_t bytes; };
   std::vector<Field> f = {
-      {(void**)&P.wp, (size_t)c.max_points * 3 * EN * 8},
-      {(void**)&P.n_points, EN * 4},
-      {(void**)&P.route_len, EN * 8},
-      {(void**)&P.radius, EN * 8},
-      {(void**)&P.prio, EN * 8},
-      {(void**)&P.bld, (size_t)(c.num_buildings > 0 ? c.num_buildings : 1) * 4 * 8},
-      {(void**)&P.pow95, (size_t)c.max_points * 8},
-      {(void**)&P.px, EN * 8}, {(void**)&P.py, EN * 8}, {(void**)&P.pz, EN * 8},
-      {(void**)&P.vx, EN * 8}, {(void**)&P.vy, EN * 8}, {(void**)&P.vz, EN * 8},
-      {(void**)&P.yaw, EN * 8}, {(void**)&P.pitch, EN * 8}, {(void**)&P.real_len, EN * 8},
-      {(void**)&P.max_dev, EN * 8}, {(void**)&P.extra_len, EN * 8},
-      {(void**)&P.wp_idx, EN * 4}, {(void**)&P.arrive, EN}, {(void**)&P.dest, EN},
+      {(void**)&P.f64, nf * S * 8},
+      {(void**)&P.i32, ni * S * 4},
+      {(void**)&P.u8, 2 * S},
+      {(void**)&C.bld, (size_t)(c.num_buildings > 0 ? c.num_buildings : 1) * 4 * 8},
+      {(void**)&C.pow95, (size_t)c.max_points * 8},
       {(void**)&P.err, 256},
-      {(void**)&P.row_iet, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 8},
-      {(void**)&P.row_pk, (size_t)(c.neighbors_num > 0 ? c.neighbors_num : 1) * EN * 4},
+      {(void**)&P.cold_, sizeof(rvo3d::Cold)},
   };
   size_t total = 0;
   for (auto& x : f) total += align_up(x.bytes, 256);
@@ -87,6 +85,7 @@ int carve(rvo3d_env* h) {
     *x.slot = static_cast<char*>(h->arena) + off;
     off += align_up(x.bytes, 256);
   }
+  HIP_TRY(hipMemcpy((void*)P.cold_, &C, sizeof C, hipMemcpyHostToDevice));  // complete by now
   return RVO3D_OK;
 }
 
@@ -151,16 +150,20 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   if (!h) return fail(RVO3D_ERR_INVALID, "out of host memory");
   h->cfg = *cfg;
   Params& P = h->P;
+  rvo3d::Cold& C = h->cold;
   std::memset(&P, 0, sizeof P);
+  std::memset(&C, 0, sizeof C);
   P.E = cfg->num_envs; P.N = cfg->num_drones; P.P = cfg->max_points;
-  P.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
+  C.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
   P.W = 12 + 9 * P.nm;
   if (const char* ab = std::getenv("RVO3D_ABLATE")) P.ablate = std::atoi(ab);  // diagnostics only
-  P.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
-  for (int k = 0; k < 3; ++k) P.map[k] = cfg->map_size[k];
+  if (const char* sg = std::getenv("RVO3D_STAGGER")) C.stagger = std::atoi(sg);
+  if (const char* sp = std::getenv("RVO3D_STAGGER_PRIO")) C.stagger_prio = std::atoi(sp);
+  C.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
+  for (int k = 0; k < 3; ++k) C.map[k] = cfg->map_size[k];
   P.T10 = sq_threshold(10.0);  // rvo_inter.py:96
-  P.T5 = sq_threshold(5.0);    // rvo_inter.py:104
-  P.T04 = sq_threshold(0.4);   // drone.py:15 goal_threshold
+  C.T5 = sq_threshold(5.0);    // rvo_inter.py:104
+  C.T04 = sq_threshold(0.4);   // drone.py:15 goal_threshold
   {
     // fp32 candidate filter (stage G).  Coordinates are centred on the map and
     // assumed within cmax of it (envs with a drone further out bypass the filter).
@@ -168,17 +171,17 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     // of two <= eD = u*(2*cmax + 2*10.5); a squared distance at |d| <= 10.5 is off by
     // <= 2*sqrt(3)*10.5*eD + 3*eD^2 + 8u*10.5^2; v.rel by <= |v|_1*(eD + 4u*10.5).
     // Every band below is twice its bound.
-    double mx = std::fmax(P.map[0], std::fmax(P.map[1], P.map[2]));
+    double mx = std::fmax(C.map[0], std::fmax(C.map[1], C.map[2]));
     if (!(mx > 0)) mx = 1.0;
-    for (int k = 0; k < 3; ++k) P.cen[k] = 0.5 * P.map[k];
+    for (int k = 0; k < 3; ++k) C.cen[k] = 0.5 * C.map[k];
     const double cmax = 0.75 * mx + 16.0;
     const double u = std::ldexp(1.0, -24);
     const double eD = u * (2.0 * cmax + 21.0);
     const double band = 2.0 * (2.0 * 1.7320508 * 10.5 * eD + 3.0 * eD * eD + 8.0 * u * 110.25);
-    P.cmax = (float)cmax;
+    C.cmax = (float)cmax;
     P.band = std::nextafter((float)band, INFINITY);
     P.t10f = std::nextafter((float)(P.T10 + band), INFINITY);
-    P.kdot = std::nextafter((float)(2.0 * (eD + 4.0 * u * 10.5) * 1.001), INFINITY);
+    C.kdot = std::nextafter((float)(2.0 * (eD + 4.0 * u * 10.5) * 1.001), INFINITY);
     // stage X1 (wave mode).  With gap = d^2 - R^2 >= x1_gap = 512*band the relative
     // error of gap is <= 1/1024 and |rel| >= sqrt(gap); a direction cosine then
     // carries <= cs = 4*(sqrt(3)*eD/sqrt(gap) + 8u) of error.  K^2 is compared with
@@ -208,23 +211,23 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   }
   P.epb = epb;
   // zero-fill geometry: units per row of the VO region (float2 if rows are 8-B aligned)
-  P.zf_div = (uint32_t)((P.W & 1) == 0 ? (P.W - 12) / 2 : (P.W - 12));
-  P.zf_magic = 0;
-  if (P.zf_div > 0) {
-    const uint32_t m = (uint32_t)(((1ull << 32) + P.zf_div - 1) / P.zf_div);
+  C.zf_div = (uint32_t)((P.W & 1) == 0 ? (P.W - 12) / 2 : (P.W - 12));
+  C.zf_magic = 0;
+  if (C.zf_div > 0) {
+    const uint32_t m = (uint32_t)(((1ull << 32) + C.zf_div - 1) / C.zf_div);
     bool ok = true;
-    const uint64_t qmax = (uint64_t)threads * P.zf_div;
-    for (uint64_t q = 0; q < qmax && ok; ++q) ok = ((q * m) >> 32) == q / P.zf_div;
+    const uint64_t qmax = (uint64_t)threads * C.zf_div;
+    for (uint64_t q = 0; q < qmax && ok; ++q) ok = ((q * m) >> 32) == q / C.zf_div;
     if (!ok) {
       delete h;
       return fail(RVO3D_ERR_INVALID, "neighbors_num too large for the zero-fill index trick");
     }
-    P.zf_magic = m;
+    C.zf_magic = m;
   }
-  P.zf_q = 0; P.zf_m40 = 0;
+  C.zf_q = 0; C.zf_m40 = 0;
   if ((P.W & 1) == 0) {
-    P.zf_q = (uint32_t)(P.W / 2);  // row bytes / 8
-    P.zf_m40 = ((1ull << 40) + P.zf_q - 1) / P.zf_q;
+    C.zf_q = (uint32_t)(P.W / 2);  // row bytes / 8
+    C.zf_m40 = ((1ull << 40) + C.zf_q - 1) / C.zf_q;
   }
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;
@@ -264,7 +267,8 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   if (rc) return rc;
   if (!waypoints || !n_points) return fail(RVO3D_ERR_INVALID, "waypoints / n_points are required");
   const Params& P = h->P;
-  if (P.nb > 0 && !buildings) return fail(RVO3D_ERR_INVALID, "buildings required when num_buildings > 0");
+  const rvo3d::Cold& C = h->cold;
+  if (C.nb > 0 && !buildings) return fail(RVO3D_ERR_INVALID, "buildings required when num_buildings > 0");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t EN = (size_t)P.E * P.N;
   std::vector<double> wp((size_t)P.P * 3 * EN), rl(EN), rad(EN), pri(EN), p95(P.P);
@@ -287,15 +291,17 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
     pri[g] = priority ? priority[g] : 5.0;
   }
   for (int k = 0; k < P.P; ++k) p95[k] = std::pow(0.95, (double)k);  // ir_gym.py:283
-  HIP_TRY(hipMemcpyAsync((void*)P.wp, wp.data(), wp.size() * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync((void*)P.n_points, n_points, EN * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync((void*)P.route_len, rl.data(), EN * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync((void*)P.radius, rad.data(), EN * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync((void*)P.prio, pri.data(), EN * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync((void*)P.pow95, p95.data(), (size_t)P.P * 8, hipMemcpyHostToDevice, s));
-  if (P.nb > 0)
-    HIP_TRY(hipMemcpyAsync((void*)P.bld, buildings, (size_t)P.nb * 32, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(P.extra_len, 0, EN * 8, s));
+  // [P][3] rows of EN doubles into arrays of stride S
+  HIP_TRY(hipMemcpy2DAsync((void*)P.wp(0, 0), (size_t)P.S * 8, wp.data(), EN * 8, EN * 8,
+                           (size_t)P.P * 3, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.n_points(), n_points, EN * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.route_len(), rl.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.radius(), rad.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)P.prio(), pri.data(), EN * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync((void*)C.pow95, p95.data(), (size_t)P.P * 8, hipMemcpyHostToDevice, s));
+  if (C.nb > 0)
+    HIP_TRY(hipMemcpyAsync((void*)C.bld, buildings, (size_t)C.nb * 32, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(P.extra_len(), 0, EN * 8, s));
   const int tb = 256;
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P,
                      (const uint8_t*)nullptr, (const uint8_t*)nullptr);
@@ -332,7 +338,7 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   if (!obs || !vo_count) return fail(RVO3D_ERR_INVALID, "obs / vo_count are required");
   Params P = h->P;
   P.obs = obs; P.vo_count = vo_count;
-  P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
+  P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   return launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
 }
 
@@ -348,7 +354,7 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   Params P = h->P;
   P.actions = actions; P.action_f64 = action_dtype == RVO3D_F64;
   P.obs = obs; P.vo_count = vo_count; P.reward = reward;
-  P.zf16 = (P.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
+  P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
   hipStream_t s = static_cast<hipStream_t>(stream);
   return autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
@@ -401,9 +407,9 @@ int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
 int rvo3d_state_ptrs(rvo3d_env* h, rvo3d_state_view* out) {
   if (!h || !out) return fail(RVO3D_ERR_INVALID, "null argument");
   const Params& P = h->P;
-  out->px = P.px; out->py = P.py; out->pz = P.pz; out->vx = P.vx; out->vy = P.vy; out->vz = P.vz;
-  out->yaw = P.yaw; out->pitch = P.pitch; out->real_len = P.real_len; out->max_dev = P.max_dev;
-  out->extra_len = P.extra_len; out->wp_idx = P.wp_idx; out->arrive = P.arrive; out->dest = P.dest;
+  out->px = P.px(); out->py = P.py(); out->pz = P.pz(); out->vx = P.vx(); out->vy = P.vy(); out->vz = P.vz();
+  out->yaw = P.yaw(); out->pitch = P.pitch(); out->real_len = P.real_len(); out->max_dev = P.max_dev();
+  out->extra_len = P.extra_len(); out->wp_idx = P.wp_idx(); out->arrive = P.arrive(); out->dest = P.dest();
   return RVO3D_OK;
 }
 
@@ -416,18 +422,18 @@ int rvo3d_get_state(rvo3d_env* h, double* pos, double* vel, double* yaw, double*
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int EN = P.E * P.N;
   const dim3 grid((EN + 255) / 256), blk(256);
-  if (pos) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.px, P.py, P.pz, pos, EN);
-  if (vel) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.vx, P.vy, P.vz, vel, EN);
+  if (pos) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.px(), P.py(), P.pz(), pos, EN);
+  if (vel) hipLaunchKernelGGL(rvo3d::soa_to_aos3, grid, blk, 0, s, P.vx(), P.vy(), P.vz(), vel, EN);
   HIP_TRY(hipGetLastError());
   const hipMemcpyKind k = hipMemcpyDeviceToDevice;
-  if (yaw) HIP_TRY(hipMemcpyAsync(yaw, P.yaw, (size_t)EN * 8, k, s));
-  if (pitch) HIP_TRY(hipMemcpyAsync(pitch, P.pitch, (size_t)EN * 8, k, s));
-  if (real_len) HIP_TRY(hipMemcpyAsync(real_len, P.real_len, (size_t)EN * 8, k, s));
-  if (max_dev) HIP_TRY(hipMemcpyAsync(max_dev, P.max_dev, (size_t)EN * 8, k, s));
-  if (extra_len) HIP_TRY(hipMemcpyAsync(extra_len, P.extra_len, (size_t)EN * 8, k, s));
-  if (wp_idx) HIP_TRY(hipMemcpyAsync(wp_idx, P.wp_idx, (size_t)EN * 4, k, s));
-  if (arrive) HIP_TRY(hipMemcpyAsync(arrive, P.arrive, (size_t)EN, k, s));
-  if (dest) HIP_TRY(hipMemcpyAsync(dest, P.dest, (size_t)EN, k, s));
+  if (yaw) HIP_TRY(hipMemcpyAsync(yaw, P.yaw(), (size_t)EN * 8, k, s));
+  if (pitch) HIP_TRY(hipMemcpyAsync(pitch, P.pitch(), (size_t)EN * 8, k, s));
+  if (real_len) HIP_TRY(hipMemcpyAsync(real_len, P.real_len(), (size_t)EN * 8, k, s));
+  if (max_dev) HIP_TRY(hipMemcpyAsync(max_dev, P.max_dev(), (size_t)EN * 8, k, s));
+  if (extra_len) HIP_TRY(hipMemcpyAsync(extra_len, P.extra_len(), (size_t)EN * 8, k, s));
+  if (wp_idx) HIP_TRY(hipMemcpyAsync(wp_idx, P.wp_idx(), (size_t)EN * 4, k, s));
+  if (arrive) HIP_TRY(hipMemcpyAsync(arrive, P.arrive(), (size_t)EN, k, s));
+  if (dest) HIP_TRY(hipMemcpyAsync(dest, P.dest(), (size_t)EN, k, s));
   return RVO3D_OK;
 }
 
@@ -441,18 +447,18 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int EN = P.E * P.N;
   const dim3 grid((EN + 255) / 256), blk(256);
-  if (pos) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, pos, P.px, P.py, P.pz, EN);
-  if (vel) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, vel, P.vx, P.vy, P.vz, EN);
+  if (pos) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, pos, P.px(), P.py(), P.pz(), EN);
+  if (vel) hipLaunchKernelGGL(rvo3d::aos3_to_soa, grid, blk, 0, s, vel, P.vx(), P.vy(), P.vz(), EN);
   HIP_TRY(hipGetLastError());
   const hipMemcpyKind k = hipMemcpyDeviceToDevice;
-  if (yaw) HIP_TRY(hipMemcpyAsync(P.yaw, yaw, (size_t)EN * 8, k, s));
-  if (pitch) HIP_TRY(hipMemcpyAsync(P.pitch, pitch, (size_t)EN * 8, k, s));
-  if (real_len) HIP_TRY(hipMemcpyAsync(P.real_len, real_len, (size_t)EN * 8, k, s));
-  if (max_dev) HIP_TRY(hipMemcpyAsync(P.max_dev, max_dev, (size_t)EN * 8, k, s));
-  if (extra_len) HIP_TRY(hipMemcpyAsync(P.extra_len, extra_len, (size_t)EN * 8, k, s));
-  if (wp_idx) HIP_TRY(hipMemcpyAsync(P.wp_idx, wp_idx, (size_t)EN * 4, k, s));
-  if (arrive) HIP_TRY(hipMemcpyAsync(P.arrive, arrive, (size_t)EN, k, s));
-  if (dest) HIP_TRY(hipMemcpyAsync(P.dest, dest, (size_t)EN, k, s));
+  if (yaw) HIP_TRY(hipMemcpyAsync(P.yaw(), yaw, (size_t)EN * 8, k, s));
+  if (pitch) HIP_TRY(hipMemcpyAsync(P.pitch(), pitch, (size_t)EN * 8, k, s));
+  if (real_len) HIP_TRY(hipMemcpyAsync(P.real_len(), real_len, (size_t)EN * 8, k, s));
+  if (max_dev) HIP_TRY(hipMemcpyAsync(P.max_dev(), max_dev, (size_t)EN * 8, k, s));
+  if (extra_len) HIP_TRY(hipMemcpyAsync(P.extra_len(), extra_len, (size_t)EN * 8, k, s));
+  if (wp_idx) HIP_TRY(hipMemcpyAsync(P.wp_idx(), wp_idx, (size_t)EN * 4, k, s));
+  if (arrive) HIP_TRY(hipMemcpyAsync(P.arrive(), arrive, (size_t)EN, k, s));
+  if (dest) HIP_TRY(hipMemcpyAsync(P.dest(), dest, (size_t)EN, k, s));
   return RVO3D_OK;
 }
 

@@ -42,47 +42,87 @@ constexpr int kMaxThreads = 512;
 constexpr double kCosD = 0.999999995;              // cos(1e-4) rounded down
 constexpr double kSinD = 1.0000000000e-4;          // >= sin(1e-4)
 
+// Parameters that are used in one place each, outside the pair loops.  They live in device
+// memory and are read through the constant address space (scalar loads at the point of use)
+// instead of riding along in the kernel-argument registers for the whole kernel.
+struct Cold {
+  double map[3];
+  double T5, T04;     // max{x : sqrt(x) <= 5 | 0.4}  (rvo_inter.py:104; drone.py:15)
+  double cen[3];      // fp32 candidate filter (stage G): centre,
+  double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
+  unsigned long long zf_m40;  // ceil(2^40 / zf_q)
+  float cmax;         // |centred coordinate| bound the bands were computed for
+  float kdot;         // fp32 error bound of v.rel per unit |v|_1
+  uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
+  uint32_t zf_magic;  // ceil(2^32 / zf_div)
+  uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
+  int nb;
+  int stagger;        // diagnostics: wave slot s of a SIMD starts s * stagger * 64 cycles late
+  int stagger_prio;   // diagnostics: issue priority per wave slot
+  const double* bld;       // [nb][4]
+  const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
+};
+typedef const __attribute__((address_space(4))) Cold ColdC;
+
 struct Params {
-  int E, N, P, nb, nm, env_train, epb, W;
+  int E, N, P, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
   int action_mode;    // 0: absolute action; 1: policy increment (trainer glue, multi_ppo.py:196-205)
   float acceler;      // ir_gym.acceler as numpy sees it next to a float32 array (float32)
   int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
-  uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
-  uint32_t zf_magic;  // ceil(2^32 / zf_div)
-  uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
-  unsigned long long zf_m40;  // ceil(2^40 / zf_q)
   int zf16;           // per call: obs is 16-B aligned and W is even -> 16-B zero-fill
-  double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
-  double map[3];
-  double T10, T5, T04;  // max{x : sqrt(x) <= 10 | 5 | 0.4}  (rvo_inter.py:96,104; drone.py:15)
-  // fp32 candidate filter (stage G): centre, coordinate bound and error bands
-  double cen[3];
-  float cmax;      // |centred coordinate| bound the bands were computed for
+  double T10;         // max{x : sqrt(x) <= 10}  (rvo_inter.py:96)
+  // fp32 candidate filter (stage G): error bands
   float t10f;      // T10 + band, rounded up
   float band;      // fp32 error bound of a squared distance at <= 10.5 m
-  float kdot;      // fp32 error bound of v.rel per unit |v|_1
   // fp32 cone pre-filter (stage X1)
   int nw;          // ceil(N / 64) rounded up to a power of two: words per request mask
   float x1_gap;    // below this d2 - R^2 the cone filter is skipped (pair passes)
   float x1_k2;     // slack factor on K^2
   float x1_cs2;    // (cos-space error bound)^2: dp < 0 and dp^2 > cs2*d2*w2 is surely outside
-  // static world (SoA over EN = E*N)
-  const double* wp;        // [P][3][EN]
-  const int32_t* n_points; // [EN]
-  const double* route_len; // [EN]
-  const double* radius;    // [EN]
-  const double* prio;      // [EN]
-  const double* bld;       // [nb][4]
-  const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
+  // All per-drone arrays live in one arena, struct-of-arrays with a common element stride
+  // S = EN rounded up to 64 (EN = E*N): array k of a block starts at element k*S.  Three base
+  // pointers instead of thirty keep the kernel's scalar registers free of spills.
+  //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | route_len radius prio |
+  //        wp [P][3] | row_iet [nm]      i32: wp_idx n_points | row_pk [nm]      u8: arrive dest
+  double* f64;
+  int32_t* i32;
+  uint8_t* u8;
+  uint32_t S;
+  enum { F_PX, F_PY, F_PZ, F_VX, F_VY, F_VZ, F_YAW, F_PITCH, F_REAL_LEN, F_MAX_DEV, F_EXTRA_LEN,
+         F_ROUTE_LEN, F_RADIUS, F_PRIO, F_WP };
+  __host__ __device__ double* f(int k) const { return f64 + (size_t)k * S; }
   // mutable state
-  double *px, *py, *pz, *vx, *vy, *vz, *yaw, *pitch, *real_len, *max_dev, *extra_len;
-  int32_t* wp_idx;
-  uint8_t *arrive, *dest;
+  __host__ __device__ double* px() const { return f(F_PX); }
+  __host__ __device__ double* py() const { return f(F_PY); }
+  __host__ __device__ double* pz() const { return f(F_PZ); }
+  __host__ __device__ double* vx() const { return f(F_VX); }
+  __host__ __device__ double* vy() const { return f(F_VY); }
+  __host__ __device__ double* vz() const { return f(F_VZ); }
+  __host__ __device__ double* yaw() const { return f(F_YAW); }
+  __host__ __device__ double* pitch() const { return f(F_PITCH); }
+  __host__ __device__ double* real_len() const { return f(F_REAL_LEN); }
+  __host__ __device__ double* max_dev() const { return f(F_MAX_DEV); }
+  __host__ __device__ double* extra_len() const { return f(F_EXTRA_LEN); }
+  __host__ __device__ int32_t* wp_idx() const { return i32; }
+  __host__ __device__ uint8_t* arrive() const { return u8; }
+  __host__ __device__ uint8_t* dest() const { return u8 + S; }
+  // static world
+  __host__ __device__ double* route_len() const { return f(F_ROUTE_LEN); }
+  __host__ __device__ double* radius() const { return f(F_RADIUS); }
+  __host__ __device__ double* prio() const { return f(F_PRIO); }
+  __host__ __device__ double* wp(int k, int c) const { return f(F_WP + 3 * k + c); }  // [P][3]
+  __host__ __device__ int32_t* n_points() const { return i32 + S; }
+  // kept VO rows of the sweep in flight, [nm] arrays (touched only when a pair is flagged)
+  __host__ __device__ double* row_iet(int s) const { return f(F_WP + 3 * P + s); }  // 1/(t+0.2)
+  __host__ __device__ uint32_t* row_pk(int s) const {                    // (alpha*100) << 16 | j
+    return reinterpret_cast<uint32_t*>(i32) + (size_t)(2 + s) * S;
+  }
+  __host__ __device__ static size_t f64_arrays(int P_, int nm_) { return F_WP + 3 * (size_t)P_ + (nm_ > 0 ? nm_ : 1); }
+  __host__ __device__ static size_t i32_arrays(int nm_) { return 2 + (size_t)(nm_ > 0 ? nm_ : 1); }
   uint32_t* err;
-  // kept VO rows of the sweep in flight, [nm][EN] each (touched only when a pair is flagged)
-  double* row_iet;     // 1 / (t + 0.2), ascending urgency
-  uint32_t* row_pk;    // (alpha * 100) << 16 | j
+  const Cold* cold_;   // device copy of the rarely used parameters
+  __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
   unsigned long long* dbg;  // diagnostics: per-workgroup s_memtime stamps [blocks][16], or null
   // per-call I/O
   const void* actions;
@@ -97,6 +137,20 @@ struct Params {
 #define RVO3D_STAMP(i)                                                                  \
   do {                                                                                  \
     if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+// issue priority of this wave (s_setprio takes an immediate)
+__device__ __forceinline__ void set_prio(unsigned p) {
+  if (p == 0) __builtin_amdgcn_s_setprio(0);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(3);
+}
+// stagger_prio 2: rotate the priority of the waves of a SIMD at every phase boundary
+#define RVO3D_PRIO(phase)                                                     \
+  do {                                                                        \
+    if (P.cold().stagger_prio == 2) set_prio((wslot + (unsigned)(phase)) & 3u);      \
+    else if (P.cold().stagger_prio == 4) set_prio((wslot + ((unsigned)(phase) >> 1)) & 3u); \
   } while (0)
 
 // ---- arithmetic primitives -------------------------------------------------
@@ -163,7 +217,7 @@ __device__ __forceinline__ void des_vel(const Params& P, const double p[3], cons
                                         double out[3]) {
   const double dx = cur[0] - p[0], dy = cur[1] - p[1], dz = cur[2] - p[2];
   const double d2 = dot3b(dx, dy, dz, dx, dy, dz);
-  if (d2 > P.T04) {  // norm > goal_threshold
+  if (d2 > P.cold().T04) {  // norm > goal_threshold
     const double inv = 1000.0 / __builtin_sqrt(d2);
     const double ux = dx * inv, uy = dy * inv, uz = dz * inv;
     double kx = __builtin_rint(ux), ky = __builtin_rint(uy), kz = __builtin_rint(uz);
@@ -201,7 +255,7 @@ __device__ __forceinline__ double deviation(const double a[3], const double b[3]
 
 __device__ __forceinline__ bool arrived(const Params& P, const double p[3], const double d[3]) {
   const double x = p[0] - d[0], y = p[1] - d[1], z = p[2] - d[2];
-  return dot3b(x, y, z, x, y, z) <= P.T04;  // norm <= 0.4, drone.py:172
+  return dot3b(x, y, z, x, y, z) <= P.cold().T04;  // norm <= 0.4, drone.py:172
 }
 
 // vel_obs3D.cal_vo_exp_tim (vel_obs3D.py:145-182)
@@ -361,9 +415,9 @@ __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, co
 // kept.  The order is total, so the result does not depend on insertion order.
 __device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, int lbase,
                                           const Drone& S, const PairOut& po, int j, int kept) {
-  const size_t T = (size_t)P.E * P.N;  // slot stride of the row scratch
-  double* const iet = P.row_iet + g;
-  uint32_t* const pk = P.row_pk + g;
+  const size_t T = P.S;  // slot stride of the row scratch
+  double* const iet = P.row_iet(0) + g;
+  uint32_t* const pk = P.row_pk(0) + g;
   // position among kept rows: first slot whose row is more urgent than the new one
   int pos = kept;
   for (int s = 0; s < kept; ++s) {
@@ -405,10 +459,10 @@ __device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el,
                                           bool active, const double p[3], const double v[3],
                                           const double az[3], double r, double prio) {
   if (!active) return;
-  const double cx = p[0] - P.cen[0], cy = p[1] - P.cen[1], cz = p[2] - P.cen[2];
+  const double cx = p[0] - P.cold().cen[0], cy = p[1] - P.cold().cen[1], cz = p[2] - P.cold().cen[2];
   const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
   const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
-                         P.kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
+                         P.cold().kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
                          (float)az[0], (float)az[1], (float)az[2], (float)prio};
   const int o = el * 2 * P.N + d, os = el * P.N + d;
 #pragma unroll
@@ -416,7 +470,7 @@ __device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el,
     if (k == WX || k == WY || k == WZ || k == WR) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
     else L.w[k][os] = val[k];
   }
-  const double cm = (double)P.cmax;
+  const double cm = (double)P.cold().cmax;
   if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
     L.far[el] = 1;
 }
@@ -504,69 +558,122 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     valid_offsets<NW>(N, d, valid);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
+      if (ROWS && !TOUCH) RVO3D_STAMP(10);
       uint32_t cand = far ? valid[w]
                           : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
       if (P.ablate & 64) cand = 0;
-      while (cand) {  // stage X1: both directions of one candidate pair
-        const int kb = __builtin_ctz(cand);
+      if (ROWS && !TOUCH) RVO3D_STAMP(11);
+      // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd
+      // count repeats its last candidate: the requests are idempotent ORs)
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
+      const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};
+      const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
+                taz = {2.f * maz, 2.f * maz};
+      const int fr = far ? 1 : 0;
+      while (cand) {
+        const int kb0 = __builtin_ctz(cand);
         cand &= cand - 1;
-        const int off = 32 * w + kb + 1;
-        const int o = o0 + off;
-        int jd = d + off;
-        if (jd >= N) jd -= N;
-        const int oj_ = el * N + jd;  // the neighbour's slot in the single-copy arrays
+        const bool two = cand != 0u;
+        const int kb1 = two ? __builtin_ctz(cand) : kb0;
+        cand &= cand - 1;
+        const int off0 = 32 * w + kb0 + 1, off1 = 32 * w + kb1 + 1;
+        const int oa = o0 + off0, ob = o0 + off1;
+        int jd0 = d + off0, jd1 = d + off1;
+        if (jd0 >= N) jd0 -= N;
+        if (jd1 >= N) jd1 -= N;
+        const int ja = el * N + jd0, jb = el * N + jd1;  // slots in the single-copy arrays
+#define RVO3D_LD2(K, i0, i1) ((v2f){L.w[K][i0], L.w[K][i1]})
         // straight-line fp32; booleans are combined bitwise on purpose (no branches)
-        const float dx = L.w[WX][o] - mex, dy = L.w[WY][o] - mey, dz = L.w[WZ][o] - mez;
-        const float jvx = L.w[WVX][oj_], jvy = L.w[WVY][oj_], jvz = L.w[WVZ][oj_];
-        const float jr = L.w[WR][o], jkd = L.w[WKD][oj_], jprio = L.w[WPRIO][oj_];
-        const float ajx = zero_act ? 0.f : L.w[WAX][oj_], ajy = zero_act ? 0.f : L.w[WAY][oj_],
-                    ajz = zero_act ? 0.f : L.w[WAZ][oj_];
-        const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float rs = jr + mer;
-        const float rs2 = rs * rs;
-        const int touch = TOUCH & (int)(d2 <= __builtin_fmaf(rs2, 1.00001f, P.band));
+        const v2f dx = RVO3D_LD2(WX, oa, ob) - mex2, dy = RVO3D_LD2(WY, oa, ob) - mey2,
+                  dz = RVO3D_LD2(WZ, oa, ob) - mez2;
+        const v2f jvx = RVO3D_LD2(WVX, ja, jb), jvy = RVO3D_LD2(WVY, ja, jb),
+                  jvz = RVO3D_LD2(WVZ, ja, jb);
+        const v2f jr = RVO3D_LD2(WR, oa, ob), jkd = RVO3D_LD2(WKD, ja, jb),
+                  jprio = RVO3D_LD2(WPRIO, ja, jb);
+        const v2f z2 = {0.f, 0.f};
+        const v2f ajx = zero_act ? z2 : RVO3D_LD2(WAX, ja, jb),
+                  ajy = zero_act ? z2 : RVO3D_LD2(WAY, ja, jb),
+                  ajz = zero_act ? z2 : RVO3D_LD2(WAZ, ja, jb);
+#undef RVO3D_LD2
+        const v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        const v2f rs = jr + mer2;
+        const v2f rs2 = rs * rs;
+        const v2f tch = __builtin_elementwise_fma(rs2, (v2f){1.00001f, 1.00001f},
+                                                  (v2f){P.band, P.band});
         // possibly approaching, each direction (v.rel > -eps)
-        const int ai = __builtin_fmaf(mvz, dz, __builtin_fmaf(mvy, dy, mvx * dx)) > -mkd;
-        const int aj = __builtin_fmaf(jvz, dz, __builtin_fmaf(jvy, dy, jvx * dx)) < jkd;
+        const v2f vi = __builtin_elementwise_fma(
+            mvz2, dz, __builtin_elementwise_fma(mvy2, dy, mvx2 * dx));
+        const v2f vj = __builtin_elementwise_fma(
+            jvz, dz, __builtin_elementwise_fma(jvy, dy, jvx * dx));
         // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
-        const float gap = d2 - rs2;  // d^2 - R^2
-        const int filt = (int)(gap >= P.x1_gap) & (int)(jprio == mprio);
+        const v2f gap = d2 - rs2;  // d^2 - R^2
         // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
-        const float K = 0.999998f * __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap, 0.f)) - 2.0e-3f * rs;
-        const float K2 = K * K * P.x1_k2;
-        const int kpos = K > 0.f;
-        const float hx = 0.5f * (mvx + jvx), hy = 0.5f * (mvy + jvy), hz = 0.5f * (mvz + jvz);
+        const v2f sq_ = {__builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.x, 0.f)),
+                         __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.y, 0.f))};
+        const v2f K = (v2f){0.999998f, 0.999998f} * sq_ - (v2f){2.0e-3f, 2.0e-3f} * rs;
+        const v2f K2 = K * K * (v2f){P.x1_k2, P.x1_k2};
+        const v2f hf = {0.5f, 0.5f};
+        const v2f hx = hf * (mvx2 + jvx), hy = hf * (mvy2 + jvy), hz = hf * (mvz2 + jvz);
         // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
-        const float wix = 2.f * max_ - hx, wiy = 2.f * may - hy, wiz = 2.f * maz - hz;
-        const float dpi = __builtin_fmaf(dz, wiz, __builtin_fmaf(dy, wiy, dx * wix));
-        const float wi2 = __builtin_fmaf(wiz, wiz, __builtin_fmaf(wiy, wiy, wix * wix));
+        const v2f wix = tax - hx, wiy = tay - hy, wiz = taz - hz;
+        const v2f dpi = __builtin_elementwise_fma(
+            dz, wiz, __builtin_elementwise_fma(dy, wiy, dx * wix));
+        const v2f wi2 = __builtin_elementwise_fma(
+            wiz, wiz, __builtin_elementwise_fma(wiy, wiy, wix * wix));
         // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
-        const float wjx = 2.f * ajx - hx, wjy = 2.f * ajy - hy, wjz = 2.f * ajz - hz;
-        const float dpj = -__builtin_fmaf(dz, wjz, __builtin_fmaf(dy, wjy, dx * wjx));
-        const float wj2 = __builtin_fmaf(wjz, wjz, __builtin_fmaf(wjy, wjy, wjx * wjx));
-        const float cs = P.x1_cs2 * d2;
+        const v2f two2 = {2.f, 2.f};
+        const v2f wjx = two2 * ajx - hx, wjy = two2 * ajy - hy, wjz = two2 * ajz - hz;
+        const v2f dpj = -__builtin_elementwise_fma(
+            dz, wjz, __builtin_elementwise_fma(dy, wjy, dx * wjx));
+        const v2f wj2 = __builtin_elementwise_fma(
+            wjz, wjz, __builtin_elementwise_fma(wjy, wjy, wjx * wjx));
+        const v2f cs = (v2f){P.x1_cs2, P.x1_cs2} * d2;
+        const v2f dpi2 = dpi * dpi, dpj2 = dpj * dpj;
+        const v2f ci = cs * wi2, cj = cs * wj2, ki = wi2 * K2, kj = wj2 * K2;
         // surely outside: cos < -cs, or 0 <= cos < cos(alpha + delta) with slack
-        const int oi = ((int)(dpi < 0.f) & (int)(dpi * dpi > cs * wi2)) |
-                       ((int)(dpi >= 0.f) & kpos & (int)(dpi * dpi < wi2 * K2));
-        const int oj = ((int)(dpj < 0.f) & (int)(dpj * dpj > cs * wj2)) |
-                       ((int)(dpj >= 0.f) & kpos & (int)(dpj * dpj < wj2 * K2));
-        const int fr = far ? 1 : 0;
-        const bool pi = (fr | touch | (ai & ~(filt & oi))) & 1;
-        const bool pj = (fr | touch | (aj & ~(filt & oj))) & 1;
-        if (pi) {
-          if (NW == 1) m2r |= 1ull << jd;
-          else atomicOr(&L.mask2[lane * NW + (jd >> 6)], 1ull << (jd & 63));
+#define RVO3D_X1_HALF(c, jd, pi, pj)                                                          \
+        {                                                                                     \
+          const int touch = TOUCH & (int)(d2.c <= tch.c);                                     \
+          const int ai = vi.c > -mkd, aj = vj.c < jkd.c;                                      \
+          const int filt = (int)(gap.c >= P.x1_gap) & (int)(jprio.c == mprio);                \
+          const int kpos = K.c > 0.f;                                                         \
+          const int oi = ((int)(dpi.c < 0.f) & (int)(dpi2.c > ci.c)) |                        \
+                         ((int)(dpi.c >= 0.f) & kpos & (int)(dpi2.c < ki.c));                 \
+          const int oj = ((int)(dpj.c < 0.f) & (int)(dpj2.c > cj.c)) |                        \
+                         ((int)(dpj.c >= 0.f) & kpos & (int)(dpj2.c < kj.c));                 \
+          pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
+          pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
         }
-        if (pj) atomicOr(&L.mask2[(el * N + jd) * NW + (d >> 6)], 1ull << (d & 63));
+        bool pi0, pj0, pi1, pj1;
+        RVO3D_X1_HALF(x, jd0, pi0, pj0)
+        RVO3D_X1_HALF(y, jd1, pi1, pj1)
+#undef RVO3D_X1_HALF
+        pi1 &= two; pj1 &= two;
+        if (NW == 1) {
+          m2r |= ((unsigned long long)pi0 << jd0) | ((unsigned long long)pi1 << jd1);
+        } else {
+          if (pi0) atomicOr(&L.mask2[lane * NW + (jd0 >> 6)], 1ull << (jd0 & 63));
+          if (pi1) atomicOr(&L.mask2[lane * NW + (jd1 >> 6)], 1ull << (jd1 & 63));
+        }
+        if (pj0) atomicOr(&L.mask2[(el * N + jd0) * NW + (d >> 6)], 1ull << (d & 63));
+        if (pj1) atomicOr(&L.mask2[(el * N + jd1) * NW + (d >> 6)], 1ull << (d & 63));
       }
     }
   }
+  if (ROWS && !TOUCH) RVO3D_STAMP(12);
   __syncthreads();
   if (active && !(P.ablate & 32)) {
     const int lbase = el * N;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
+#ifdef RVO3D_DIAG_COUNTS
+      if (ROWS && !TOUCH && P.dbg) {
+        atomicMax(&P.dbg[(size_t)blockIdx.x * 16 + 14], (unsigned long long)__builtin_popcountll(m2));
+        atomicAdd(&P.dbg[(size_t)blockIdx.x * 16 + 15], (unsigned long long)__builtin_popcountll(m2));
+      }
+#endif
       while (m2) {  // stage X2: exact, requested pairs only
         const int j = 64 * w + __builtin_ctzll(m2);
         m2 &= m2 - 1;
@@ -580,6 +687,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
       }
     }
   }
+  if (ROWS && !TOUCH) RVO3D_STAMP(13);
   return kept;
 }
 
@@ -637,11 +745,11 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
 // building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
 __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
   bool hit = false;
-  for (int b = 0; b < P.nb; ++b) {
-    const double bx = P.bld[4 * b], by = P.bld[4 * b + 1], bh = P.bld[4 * b + 2],
-                 br = P.bld[4 * b + 3];
+  for (int b = 0; b < P.cold().nb; ++b) {
+    const double bx = P.cold().bld[4 * b], by = P.cold().bld[4 * b + 1], bh = P.cold().bld[4 * b + 2],
+                 br = P.cold().bld[4 * b + 3];
     if (bh > S.z - 2) {
-      if (norm2sq(S.x - bx, S.y - by) <= P.T5) {  // norm <= 5
+      if (norm2sq(S.x - bx, S.y - by) <= P.cold().T5) {  // norm <= 5
         if (S.z <= bh) {
           double dis = __builtin_sqrt(sq(S.x - bx) + sq(S.y - by));
           if (dis <= S.r + br) hit = true;
@@ -652,21 +760,30 @@ __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
   return hit;
 }
 
-// Per-lane part of one observation row: np.round(concat[12 proprio, kept VO
-// rows], 2) (ir_gym.py:208-229 / :353-355).  The zero padding behind the kept
-// rows is written by zero_fill() cooperatively.
-__device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int tid, int lbase,
-                                              int g, const Drone& S, const double dv[3],
-                                              double dev, int kept) {
+// Proprioceptive part of one observation row: np.round of [state, vel, radius,
+// priority, des_vel, deviation] (ir_gym.py:208-229 / :353-355), 12 floats.  The last four
+// arrive already rounded (`tail`, made by proprio_tail before the final sweep so that the
+// fp64 values are dead across it).
+struct ProprioTail { float dv0, dv1, dv2, dev; bool bad; };
+__device__ __forceinline__ ProprioTail proprio_tail(const double dv[3], double dev) {
+  ProprioTail t;
+  t.dv0 = round2_f32(dv[0]); t.dv1 = round2_f32(dv[1]); t.dv2 = round2_f32(dv[2]);
+  t.dev = round2_f32(dev);
+  t.bad = !(finite_d(dv[0]) && finite_d(dv[1]) && finite_d(dv[2]) && finite_d(dev));
+  return t;
+}
+__device__ __forceinline__ void write_proprio(const Params& P, int g, const Drone& S,
+                                              const ProprioTail& t) {
   float* o = P.obs + (size_t)g * P.W;
-  const double v[12] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio, dv[0], dv[1], dv[2], dev};
+  const double v[8] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio};
   float f[12];
-  bool bad = false;
+  bool bad = t.bad;
 #pragma unroll
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < 8; ++k) {
     f[k] = round2_f32(v[k]);
     bad |= !finite_d(v[k]);
   }
+  f[8] = t.dv0; f[9] = t.dv1; f[10] = t.dv2; f[11] = t.dev;
   if ((P.W & 1) == 0) {  // rows are 8-B aligned
     float2* o2 = reinterpret_cast<float2*>(o);
 #pragma unroll
@@ -675,8 +792,19 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
 #pragma unroll
     for (int k = 0; k < 12; ++k) o[k] = f[k];
   }
+  if (bad) atomicOr(P.err, 1u);
+}
+
+// The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
+// iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
+// behind them (written by zero_fill()).
+__device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int tid, int lbase,
+                                              int g, const Drone& S, int kept,
+                                              bool prezeroed = false) {
+  float* o = P.obs + (size_t)g * P.W;
+  bool bad = false;
   for (int s = 0; s < kept; ++s) {
-    const uint32_t pk = P.row_pk[(size_t)s * P.E * P.N + g];
+    const uint32_t pk = P.row_pk(s)[g];
     const int j = (int)(pk & 0xffffu);
     const Drone O = lds_drone(L, lbase + j);
     const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
@@ -687,12 +815,17 @@ __device__ __forceinline__ void write_obs_row(const Params& P, const Lds& L, int
     row[3] = O.x - S.x; row[4] = O.y - S.y; row[5] = O.z - S.z;
     row[6] = (double)(pk >> 16) / 100.0;
     row[7] = pair_md(S, O);
-    row[8] = P.row_iet[(size_t)s * P.E * P.N + g];
+    row[8] = P.row_iet(s)[g];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       bad |= !finite_d(row[k]);
       o[12 + 9 * s + k] = round2_f32(row[k]);
     }
+  }
+  if (prezeroed) {  // the whole VO region was zeroed at the start of the step
+    P.vo_count[g] = kept;
+    if (bad) atomicOr(P.err, 1u);
+    return;
   }
   // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
   if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
@@ -728,19 +861,19 @@ __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid
     const uint32_t cend = (uint32_t)((rb * (unsigned)(row0 + nrows)) >> 4);
     float4* ob = reinterpret_cast<float4*>(P.obs);
     for (uint32_t c = cbeg + tid; c < cend; c += L.T) {
-      const uint32_t grow = (uint32_t)(((unsigned long long)(2u * c) * P.zf_m40) >> 40);
+      const uint32_t grow = (uint32_t)(((unsigned long long)(2u * c) * P.cold().zf_m40) >> 40);
       const uint32_t lr = grow - (uint32_t)row0;
       if (c >= L.zc[2 * lr] && c < L.zc[2 * lr + 1]) ob[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     return;
   }
-  const uint32_t per_row = P.zf_div;
+  const uint32_t per_row = P.cold().zf_div;
   if (per_row == 0) return;
   const uint32_t total = (uint32_t)nrows * per_row;
   float* base = P.obs + (size_t)row0 * P.W + 12;
   if ((P.W & 1) == 0) {
     for (uint32_t q = tid; q < total; q += L.T) {
-      const uint32_t row = (uint32_t)(((uint64_t)q * P.zf_magic) >> 32);
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.cold().zf_magic) >> 32);
       const uint32_t c = q - row * per_row;       // float2 index inside the VO region
       const uint32_t first = (9u * (uint32_t)L.kept[row] + 1u) >> 1;  // first all-zero unit
       if (c >= first)
@@ -748,7 +881,7 @@ __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid
     }
   } else {
     for (uint32_t q = tid; q < total; q += L.T) {
-      const uint32_t row = (uint32_t)(((uint64_t)q * P.zf_magic) >> 32);
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.cold().zf_magic) >> 32);
       const uint32_t c = q - row * per_row;
       if (c >= 9u * (uint32_t)L.kept[row]) base[(size_t)row * P.W + c] = 0.0f;
     }
@@ -756,16 +889,15 @@ __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid
 }
 
 __device__ __forceinline__ void load_wp(const Params& P, int g, int k, double out[3]) {
-  const size_t EN = (size_t)P.E * P.N;
-  out[0] = P.wp[((size_t)k * 3 + 0) * EN + g];
-  out[1] = P.wp[((size_t)k * 3 + 1) * EN + g];
-  out[2] = P.wp[((size_t)k * 3 + 2) * EN + g];
+  out[0] = P.wp(k, 0)[g];
+  out[1] = P.wp(k, 1)[g];
+  out[2] = P.wp(k, 2)[g];
 }
 
-// ir_gym.rvo_reward_cal (ir_gym.py:64-133) after config_vo_reward.  Returns the
-// integer k with np.round(total, 3) == k / 1000 (or inf / nan, survey Q9).
-__device__ __forceinline__ double rvo_reward_k(const double dv[3], const double a[3], bool flag,
-                                               double tmin) {
+// ir_gym.rvo_reward_cal (ir_gym.py:64-133), the part that does not depend on the sweep:
+// angle_punish + vel_penalty.  The sweep's safety term is added afterwards in the
+// reference's order, (punish + vel_penalty) + safety: rvo_reward_k().
+__device__ __forceinline__ double rvo_reward_pre(const double dv[3], const double a[3]) {
   // des_vel is already a 3-decimal value: np.round(., 3) again is the identity
   const double d0 = dv[0], d1 = dv[1], d2 = dv[2];
   const double vel_penalty = 0.2 * norm3b(a[0], a[1], a[2]) / norm3b(d0, d1, d2);
@@ -793,13 +925,17 @@ __device__ __forceinline__ double rvo_reward_k(const double dv[3], const double 
     else if (ang < kPi / 2) punish = 0;
     else punish = -4;
   }
+  return punish + vel_penalty;
+}
+// Returns the integer k with np.round(total, 3) == k / 1000 (or inf / nan, survey Q9).
+__device__ __forceinline__ double rvo_reward_k(double pre, bool flag, double tmin) {
   double safety = 0;
   if (flag) {
     double urgency = 0;
     if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
     safety = -2.5 + urgency;
   }
-  return __builtin_rint((punish + vel_penalty + safety) * 1000.0);
+  return __builtin_rint((pre + safety) * 1000.0);
 }
 
 // ir_gym.mov_reward (ir_gym.py:256-311); returns k with round(., 3) == k / 1000
@@ -808,7 +944,7 @@ __device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, 
                                                double dev, bool len_flag, double exlen) {
   if (collision) return -50000.0;  // -50
   double reward = 0;
-  if (arrive_r) reward += 3.0 * P.pow95[n_points_m1 - waypoint_num];
+  if (arrive_r) reward += 3.0 * P.cold().pow95[n_points_m1 - waypoint_num];
   if (dest_r) reward += 20.0;
   const double d = dev * 10;
   const double dev_pen = -1.5 * (2 / (1 + exp(-(d - 5) / 0.3)));
@@ -828,8 +964,10 @@ __device__ __forceinline__ float reward_f32(double k1, double k2) {
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
+// One-wave workgroups (N <= 64) are register-limited: 128 VGPRs = 4 waves per SIMD, i.e. the
+// 4096 waves of 64 x 4096 are all resident at once.  Larger N is LDS-limited (3 per SIMD).
 #ifndef RVO3D_WAVES_ATTR
-#define RVO3D_WAVES_ATTR
+#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NW == 1 ? 4 : 3)))
 #endif
 
 // The whole environment step, one launch.
@@ -846,39 +984,47 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   const int g = active ? e * N + d : 0;
   const int lbase = el * N;
   const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
+  constexpr bool LITE = (MODE == kStepAutoReset);
 
+  // Register discipline: values are loaded right before the phase that needs them and
+  // stored as soon as they are final, so that across the sweeps little more than the
+  // drone's own 8-value record and its action stay live (registers = waves per SIMD).
   RVO3D_STAMP(0);
-  double p[3] = {0, 0, 0}, v[3] = {0, 0, 0}, a[3] = {0, 0, 0};
-  double yaw = 0, pitch = 0, real_len = 0, max_dev = 0, extra_len = 0, route_len = 0;
-  double cur[3] = {0, 0, 0}, prev[3] = {0, 0, 0}, dst[3] = {0, 0, 0}, dv[3] = {0, 0, 0}, dev = 0;
-  int wpi = 1, npts = 2;
-  bool f_arrive = false, f_dest = false;
+  // HW_REG_HW_ID (id 4) bits [3:0] = wave slot on its SIMD.  The SIMD issues oldest-first, so
+  // the waves of a one-round grid finish one after the other and the last one runs alone;
+  // per-slot priorities (diagnostics: RVO3D_STAGGER_PRIO) change that order.
+  const unsigned wslot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u;
+  if (P.cold().stagger_prio == 1) set_prio(3u - wslot);
+  else if (P.cold().stagger_prio == 3) set_prio(wslot);
+  for (unsigned k = 0; k < wslot * (unsigned)P.cold().stagger; ++k) __builtin_amdgcn_s_sleep(1);
+  RVO3D_PRIO(0);
   Drone S;
-  S.r = 0.2; S.prio = 5;
+  S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;
+  double a[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  double dev = 0, max_dev = 0, pre_k = 0;
+  int wpi = 1;
 
+  // ---- phase 0: drone.dronestate on the pre-move state (drone.py:254-263)
   if (active) {
-    p[0] = P.px[g]; p[1] = P.py[g]; p[2] = P.pz[g];
-    v[0] = P.vx[g]; v[1] = P.vy[g]; v[2] = P.vz[g];
-    max_dev = P.max_dev[g];
-    wpi = P.wp_idx[g];
-    S.r = P.radius[g]; S.prio = P.prio[g];
+    S.x = P.px()[g]; S.y = P.py()[g]; S.z = P.pz()[g];
+    S.vx = P.vx()[g]; S.vy = P.vy()[g]; S.vz = P.vz()[g];
+    S.r = P.radius()[g]; S.prio = P.prio()[g];
+    max_dev = P.max_dev()[g];
+    wpi = P.wp_idx()[g];
+    double prev[3];
     load_wp(P, g, wpi, cur);
     load_wp(P, g, wpi - 1, prev);
     if (MODE != kObserve) {
-      yaw = P.yaw[g]; pitch = P.pitch[g]; real_len = P.real_len[g];
-      extra_len = P.extra_len[g]; route_len = P.route_len[g];
-      npts = P.n_points[g];
-      f_arrive = P.arrive[g] != 0; f_dest = P.dest[g] != 0;
-      load_wp(P, g, npts - 1, dst);
       if (P.action_mode == 1) {
         // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:
         //   a_inc = np.round(sample, 2)                  float32: rint(a * 100f) / 100f
         //   abs   = np.round(acceler * a_inc + vel, 2)   float32 product, widened, + float64
         const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
+        const double vv[3] = {S.vx, S.vy, S.vz};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const float r = __builtin_rintf(A[k] * 100.0f) / 100.0f;
-          const double x = (double)(P.acceler * r) + v[k];
+          const double x = (double)(P.acceler * r) + vv[k];
           a[k] = __builtin_rint(x * 100.0) / 100.0;
         }
       } else {
@@ -889,19 +1035,21 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
           const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
           a[0] = (double)A[0]; a[1] = (double)A[1]; a[2] = (double)A[2];
         }
-        if (P.act_scale > 0) {
-          a[0] = __builtin_rint(a[0] * P.act_scale) / P.act_scale;
-          a[1] = __builtin_rint(a[1] * P.act_scale) / P.act_scale;
-          a[2] = __builtin_rint(a[2] * P.act_scale) / P.act_scale;
+        if (P.cold().act_scale > 0) {
+          a[0] = __builtin_rint(a[0] * P.cold().act_scale) / P.cold().act_scale;
+          a[1] = __builtin_rint(a[1] * P.cold().act_scale) / P.cold().act_scale;
+          a[2] = __builtin_rint(a[2] * P.cold().act_scale) / P.cold().act_scale;
         }
       }
     }
-    // drone.dronestate on the pre-move state (drone.py:254-263)
+    const double p[3] = {S.x, S.y, S.z};
     des_vel(P, p, cur, dv);
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
+    if (MODE != kObserve) pre_k = rvo_reward_pre(dv, a);
   }
   RVO3D_STAMP(1);
+  RVO3D_PRIO(1);
   double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
   if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
   const double zero3[3] = {0, 0, 0};
@@ -909,12 +1057,14 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   if (tid < P.epb) { L.any_reset[tid] = 0; L.far[tid] = 0; }
   L.kept[tid] = 0;
   __syncthreads();  // flags zeroed before anyone raises them
-  L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
-  L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
+  L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
+  L.vx[tid] = S.vx; L.vy[tid] = S.vy; L.vz[tid] = S.vz;
   L.r[tid] = S.r; L.prio[tid] = S.prio;
-  stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+  {
+    const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
+    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+  }
   __syncthreads();
-  S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
 
   bool flag, collision = false;
   double tmin;
@@ -923,27 +1073,50 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision);
     if (active) {
-      write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
+      write_proprio(P, g, S, proprio_tail(dv, dev));
+      write_vo_rows(P, L, tid, lbase, g, S, kept);
       L.kept[tid] = kept;
-      P.max_dev[g] = max_dev;
+      P.max_dev()[g] = max_dev;
     }
     __syncthreads();
     zero_fill(P, L, tid, e0 * N, nrows);
     return;
   }
 
+  // diagnostic (RVO3D_ABLATE bit 128): zero the VO region of every row now, under the
+  // sweeps, instead of after them
+  const bool early_zero = (P.ablate & 128) && P.zf16;
+  if (early_zero) {
+    if (active) write_vo_rows(P, L, tid, lbase, g, S, 0);
+    __syncthreads();
+    zero_fill(P, L, tid, e0 * N, nrows);
+  }
   RVO3D_STAMP(2);
+  RVO3D_PRIO(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
-  double rew_k = 0;
   sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
                               tmin, collision);
-  if (active) rew_k = rvo_reward_k(dv, a, flag, tmin);
+  const double rew_k = rvo_reward_k(pre_k, flag, tmin);
   __syncthreads();  // everyone is done with the pre-move LDS image
   RVO3D_STAMP(3);
+  RVO3D_PRIO(3);
 
-  // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490)
+  // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490), the
+  //      post-move dronestate and the arrival flags of ir_gym.observation_reward (:168-193)
+  double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
+  bool f_dest = false;
   if (active) {
-    double speed = norm3b(v[0], v[1], v[2]);
+    double yaw = P.yaw()[g], pitch = P.pitch()[g], real_len = P.real_len()[g];
+    double extra_len = P.extra_len()[g];
+    const double route_len = P.route_len()[g];
+    const int npts = P.n_points()[g];
+    bool f_arrive = P.arrive()[g] != 0;
+    f_dest = P.dest()[g] != 0;
+    double dst[3], prev[3];
+    load_wp(P, g, npts - 1, dst);
+    load_wp(P, g, wpi - 1, prev);
+
+    double speed = norm3b(S.vx, S.vy, S.vz);
     const double acc = clampd(a[0] * 1.0, -1.0, 1.0);
     const double dyaw = clampd(a[1] * 90.0, -90.0, 90.0);
     const double dpit = clampd(a[2] * 90.0, -90.0, 90.0);
@@ -958,10 +1131,11 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       sincos(pitch * kDeg2Rad, &sp, &cp);
       nvx = speed * cp * cy; nvy = speed * cp * sy; nvz = speed * sp;
     }
-    const double q0 = p[0], q1 = p[1], q2 = p[2];
-    p[0] = p[0] + nvx; p[1] = p[1] + nvy; p[2] = p[2] + nvz;
-    v[0] = nvx; v[1] = nvy; v[2] = nvz;
-    real_len = real_len + norm3b(p[0] - q0, p[1] - q1, p[2] - q2);
+    const double q0 = S.x, q1 = S.y, q2 = S.z;
+    S.x = S.x + nvx; S.y = S.y + nvy; S.z = S.z + nvz;
+    S.vx = nvx; S.vy = nvy; S.vz = nvz;
+    real_len = real_len + norm3b(S.x - q0, S.y - q1, S.z - q2);
+    const double p[3] = {S.x, S.y, S.z};
     if (arrived(P, p, cur)) {  // drone.py:116-129
       const bool at_dst = arrived(P, p, dst);
       if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
@@ -976,19 +1150,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     des_vel(P, p, cur, dv);
     dev = deviation(prev, cur, p);
     if (dev > max_dev) max_dev = dev;
-  }
-  L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
-  L.vx[tid] = v[0]; L.vy[tid] = v[1]; L.vz[tid] = v[2];
-  stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
-  __syncthreads();
-  S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
-
-  RVO3D_STAMP(4);
-  // ---- sweep B: ir_gym.observation_reward on the post-move state (ir_gym.py:156-254)
-  bool do_reset = false, arrive_r = false, dest_r = false;
-  const int waypoint_num = wpi;
-  double exlen = 0;
-  if (active) {
+    // arrival flags (ir_gym.py:168-181)
+    bool arrive_r = false, dest_r = false;
+    const int waypoint_num = wpi;
     if (!f_arrive && arrived(P, p, cur)) { f_arrive = true; arrive_r = true; }
     if (f_arrive) {
       if (arrived(P, p, dst)) {
@@ -996,14 +1160,34 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
         if (!f_dest) { f_dest = true; dest_r = true; }
       }
     }
-    exlen = real_len - route_len + 4;
+    const double exlen = real_len - route_len + 4;
+    mov_nc = mov_reward_k(P, false, arrive_r, waypoint_num, npts - 1, dest_r, dev, exlen > 0,
+                          exlen);
     collision = building_hit(P, S);
+    if (S.x < 0 || S.x > P.cold().map[0] || S.y < 0 || S.y > P.cold().map[1] || S.z < 0 || S.z > P.cold().map[2])
+      collision = true;  // drone.drone_out_map, drone.py:213-225
+    // final for this step unless the drone is reset below
+    P.yaw()[g] = yaw; P.pitch()[g] = pitch; P.real_len()[g] = real_len; P.extra_len()[g] = extra_len;
+    P.wp_idx()[g] = wpi;
+    P.arrive()[g] = f_arrive ? 1 : 0; P.dest()[g] = f_dest ? 1 : 0;
+    P.info[g] = f_arrive ? 1 : 0;
+    P.finish[g] = f_dest ? 1 : 0;
   }
-  // In the fused auto-reset step an env that resets discards the step's VO rows
-  // (its observation is recomputed after the reset), so the wave pipeline first runs
-  // a collision-only sweep, settles the resets, and then sweeps ONCE for the rows -
-  // on the post-move state with the action, or on the post-reset state with 0.
-  constexpr bool LITE = (MODE == kStepAutoReset);
+  L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
+  L.vx[tid] = S.vx; L.vy[tid] = S.vy; L.vz[tid] = S.vz;
+  {
+    const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
+    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+  }
+  __syncthreads();
+
+  RVO3D_STAMP(4);
+  RVO3D_PRIO(4);
+  // ---- sweep B: the pair part of ir_gym.observation_reward (ir_gym.py:197).
+  // In the fused auto-reset step an env that resets discards the step's VO rows (its
+  // observation is recomputed after the reset), so a collision-only sweep runs first,
+  // the resets are settled, and then ONE sweep produces the rows - on the post-move
+  // state with the action, or on the post-reset state with action 0.
   int kept = 0;
   if (LITE) {
     if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
@@ -1011,83 +1195,67 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
                                      flag, tmin, collision);
   }
+  bool do_reset = false;
   if (active) {
-    if (p[0] < 0 || p[0] > P.map[0] || p[1] < 0 || p[1] > P.map[1] || p[2] < 0 ||
-        p[2] > P.map[2])
-      collision = true;  // drone.drone_out_map, drone.py:213-225
-    const double mr_k = mov_reward_k(P, collision, arrive_r, waypoint_num, npts - 1, dest_r,
-                                     dev, exlen > 0, exlen);
-    P.reward[g] = reward_f32(rew_k, mr_k);  // mdin.py:28
+    P.reward[g] = reward_f32(rew_k, collision ? -50000.0 : mov_nc);  // mdin.py:28
     P.done[g] = collision ? 1 : 0;
-    P.info[g] = f_arrive ? 1 : 0;
-    P.finish[g] = f_dest ? 1 : 0;
-    do_reset = (MODE == kStepAutoReset) && (collision || f_dest);
+    do_reset = LITE && (collision || f_dest);
   }
 
   RVO3D_STAMP(5);
-  if (MODE == kStepAutoReset) {
+  RVO3D_PRIO(5);
+  if (LITE) {
     if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
     if (do_reset) L.any_reset[el] = 1;
-    __syncthreads();  // sweep B reads done; any_reset visible
-    const bool env_reset = active && (L.any_reset[el] != 0);
-    if (!LITE && active && !env_reset) {  // this env keeps the step's observation: write it now
-      if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
-      L.kept[tid] = kept;
-    }
+    __syncthreads();  // sweep reads done; any_reset visible
     if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
+      double p[3];
       load_wp(P, g, 0, p);
-      v[0] = v[1] = v[2] = 0.0;
-      wpi = 1; f_arrive = false; f_dest = false;
-      real_len = 0.0; max_dev = 0.0; yaw = 0.0; pitch = 0.0;
       load_wp(P, g, 1, cur);
-      prev[0] = p[0]; prev[1] = p[1]; prev[2] = p[2];
+      S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
       des_vel(P, p, cur, dv);
-      dev = deviation(prev, cur, p);
-      if (dev > max_dev) max_dev = dev;
-      L.x[tid] = p[0]; L.y[tid] = p[1]; L.z[tid] = p[2];
+      dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
+      max_dev = dev > 0.0 ? dev : 0.0;
+      P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
+      P.real_len()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
+      L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
       L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
-      stage_f32(P, L, el, d, true, p, v, az, S.r, S.prio);
+      const double v0[3] = {0, 0, 0};
+      stage_f32(P, L, el, d, true, p, v0, az, S.r, S.prio);
     }
-    __syncthreads();
-    S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = v[0]; S.vy = v[1]; S.vz = v[2];
-    RVO3D_STAMP(6);
-    bool c2 = false;
-    if (LITE) {
-      // rows for every env: ir_gym.observation_reward's VO part (env kept its state) or
-      // ir_gym.env_observation with action 0 (env reset a drone, ir_gym.py:372-383)
-      const double* aa = env_reset ? zero3 : az;
-      kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
-                                        env_reset, flag, tmin, c2);
-      if (active) {
-        if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
-        L.kept[tid] = kept;
-      }
-    } else {
-      // ir_gym.env_observation for every env that reset a drone (ir_gym.py:372-383)
-      const int kept_c = sweep_env<NW, true, true>(P, L, tid, el, d, g, env_reset && !(P.ablate & 4),
-                                                   S, zero3, true, flag, tmin, c2);
-      if (env_reset) {
-        if (!(P.ablate & 8)) write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept_c);
-        L.kept[tid] = kept_c;
-      }
-    }
-  } else if (active) {
-    write_obs_row(P, L, tid, lbase, g, S, dv, dev, kept);
-    L.kept[tid] = kept;
   }
-
+  // everything about this drone except its VO rows is final now.  The stores wait until
+  // after the last sweep (vector memory returns in order: a load behind a store waits for
+  // it), but only the rounded floats of des_vel / deviation stay live across the sweep.
+  const ProprioTail ptail = proprio_tail(dv, dev);
+  if (LITE) {
+    __syncthreads();
+    RVO3D_STAMP(6);
+  RVO3D_PRIO(6);
+    // rows for every env: ir_gym.observation_reward's VO part (the env kept its state) or
+    // ir_gym.env_observation with action 0 (the env reset a drone, ir_gym.py:372-383)
+    const bool env_reset = active && (L.any_reset[el] != 0);
+    bool c2 = false;
+    const double* aa = env_reset ? zero3 : az;
+    kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
+                                      env_reset, flag, tmin, c2);
+  }
   RVO3D_STAMP(7);
+  RVO3D_PRIO(7);
   if (active) {
-    P.px[g] = p[0]; P.py[g] = p[1]; P.pz[g] = p[2];
-    P.vx[g] = v[0]; P.vy[g] = v[1]; P.vz[g] = v[2];
-    P.yaw[g] = yaw; P.pitch[g] = pitch; P.real_len[g] = real_len;
-    P.max_dev[g] = max_dev; P.extra_len[g] = extra_len;
-    P.wp_idx[g] = wpi;
-    P.arrive[g] = f_arrive ? 1 : 0; P.dest[g] = f_dest ? 1 : 0;
+    if (!(P.ablate & 8)) {
+      write_vo_rows(P, L, tid, lbase, g, S, kept, early_zero);
+      write_proprio(P, g, S, ptail);
+    }
+    L.kept[tid] = kept;
+    P.max_dev()[g] = max_dev;
+    P.px()[g] = S.x; P.py()[g] = S.y; P.pz()[g] = S.z;
+    P.vx()[g] = S.vx; P.vy()[g] = S.vy; P.vz()[g] = S.vz;
   }
   __syncthreads();  // L.kept complete
   RVO3D_STAMP(8);
-  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
+  RVO3D_PRIO(8);
+  if (!(P.ablate & 16) && !early_zero) zero_fill(P, L, tid, e0 * N, nrows);
   RVO3D_STAMP(9);
 }
 
@@ -1100,17 +1268,17 @@ __global__ void reset_kernel(const Params P, const uint8_t* env_mask, const uint
   if (drone_mask && !drone_mask[g]) return;
   double s[3];
   load_wp(P, g, 0, s);
-  P.px[g] = s[0]; P.py[g] = s[1]; P.pz[g] = s[2];
-  P.vx[g] = 0.0; P.vy[g] = 0.0; P.vz[g] = 0.0;
-  P.wp_idx[g] = 1; P.arrive[g] = 0; P.dest[g] = 0;
-  P.real_len[g] = 0.0; P.max_dev[g] = 0.0; P.yaw[g] = 0.0; P.pitch[g] = 0.0;
+  P.px()[g] = s[0]; P.py()[g] = s[1]; P.pz()[g] = s[2];
+  P.vx()[g] = 0.0; P.vy()[g] = 0.0; P.vz()[g] = 0.0;
+  P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
+  P.real_len()[g] = 0.0; P.max_dev()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
 }
 
 __global__ void des_vel_kernel(const Params P, double* out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P.E * P.N) return;
-  double p[3] = {P.px[g], P.py[g], P.pz[g]}, cur[3], dv[3];
-  load_wp(P, g, P.wp_idx[g], cur);
+  double p[3] = {P.px()[g], P.py()[g], P.pz()[g]}, cur[3], dv[3];
+  load_wp(P, g, P.wp_idx()[g], cur);
   des_vel(P, p, cur, dv);
   out[3 * (size_t)g] = dv[0]; out[3 * (size_t)g + 1] = dv[1]; out[3 * (size_t)g + 2] = dv[2];
 }

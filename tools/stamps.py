@@ -25,3 +25,35 @@ for i, n in enumerate(names):
 
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
+
+if s[:, 10:14].any():  # inner stamps of the final sweep (diagnostic builds only)
+    inner = np.diff(s[:, 10:14], axis=1)
+    for i, n in enumerate(["G", "X1", "sync+X2+rows"]):
+        print(f"  final sweep {n:14s} {inner[:, i].mean():9.0f} {np.median(inner[:, i]):9.0f} {np.percentile(inner[:, i], 95):9.0f}")
+    print("  X2 requests per lane: max over wave mean", s[:, 14].mean(), "p50", np.median(s[:, 14]), "p95", np.percentile(s[:, 14], 95), "max", s[:, 14].max(),
+          "| sum per wave mean", s[:, 15].mean(), "p95", np.percentile(s[:, 15], 95))
+    print("  corr(wave life, max requests) =", np.corrcoef(life, s[:, 14])[0, 1], " corr(life, sum) =", np.corrcoef(life, s[:, 15])[0, 1])
+    print("  wave life p5/p50/p95/max", np.percentile(life, [5, 50, 95, 100]))
+    print("  final sweep pre-G", (s[:, 10] - s[:, 6]).mean(), "post", (s[:, 7] - s[:, 13]).mean())
+
+# per clock-domain view: s_memtime is not synchronised across XCDs, so cluster the
+# workgroups by their start stamp (gaps > 1e6 ticks separate the domains)
+order = np.argsort(s[:, 0])
+cuts = np.where(np.diff(s[order, 0]) > 1_000_000)[0] + 1
+for grp in np.split(order, cuts):
+    sx = s[grp]
+    t0 = sx[:, 0].min()
+    st = np.sort(sx[:, 0] - t0)
+    ids = np.sort(grp)[:4]
+    print(f"  domain of wgs {ids}.. n={len(grp)}: span {sx[:, 9].max() - t0:7d}  start p50 {st[len(st)//2]:6d} "
+          f"p90 {st[int(len(st)*0.9)]:6d} max {st[-1]:6d}  end p50 {int(np.median(sx[:, 9] - t0)):7d}")
+
+# timeline of one CU: the first clock domain with exactly 16 workgroups (4 waves x 4 SIMDs)
+for grp in np.split(order, cuts):
+    if len(grp) == 16:
+        sx = s[np.sort(grp)]
+        t0 = sx[:, 0].min()
+        print("  one CU, stamps 0..9 relative to its first wave start (k cycles):")
+        for r in sx[np.argsort(sx[:, 9])]:
+            print("   ", " ".join(f"{(int(v) - int(t0)) / 1000:6.1f}" for v in r[:10]))
+        break
