@@ -1001,19 +1001,15 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   Drone S;
   S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;
   double a[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
-  double dev = 0, max_dev = 0, pre_k = 0;
+  double dev = 0, max_dev = 0;
   int wpi = 1;
 
-  // ---- phase 0: drone.dronestate on the pre-move state (drone.py:254-263)
+  // ---- phase 0: the drone's own record and its action; everything else about the pre-move
+  //      state (waypoints, des_vel, deviation) is fetched after sweep A, which needs none of it
   if (active) {
     S.x = P.px()[g]; S.y = P.py()[g]; S.z = P.pz()[g];
     S.vx = P.vx()[g]; S.vy = P.vy()[g]; S.vz = P.vz()[g];
     S.r = P.radius()[g]; S.prio = P.prio()[g];
-    max_dev = P.max_dev()[g];
-    wpi = P.wp_idx()[g];
-    double prev[3];
-    load_wp(P, g, wpi, cur);
-    load_wp(P, g, wpi - 1, prev);
     if (MODE != kObserve) {
       if (P.action_mode == 1) {
         // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:
@@ -1042,11 +1038,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
         }
       }
     }
-    const double p[3] = {S.x, S.y, S.z};
-    des_vel(P, p, cur, dv);
-    dev = deviation(prev, cur, p);
-    if (dev > max_dev) max_dev = dev;
-    if (MODE != kObserve) pre_k = rvo_reward_pre(dv, a);
   }
   RVO3D_STAMP(1);
   RVO3D_PRIO(1);
@@ -1070,6 +1061,17 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   double tmin;
 
   if (MODE == kObserve) {
+    if (active) {  // drone.dronestate (drone.py:254-263)
+      double prev[3];
+      max_dev = P.max_dev()[g];
+      wpi = P.wp_idx()[g];
+      load_wp(P, g, wpi, cur);
+      load_wp(P, g, wpi - 1, prev);
+      const double p[3] = {S.x, S.y, S.z};
+      des_vel(P, p, cur, dv);
+      dev = deviation(prev, cur, p);
+      if (dev > max_dev) max_dev = dev;
+    }
     const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision);
     if (active) {
@@ -1096,7 +1098,20 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
                               tmin, collision);
-  const double rew_k = rvo_reward_k(pre_k, flag, tmin);
+  // drone.dronestate on the pre-move state (drone.py:254-263) and the RVO reward
+  double rew_k = 0;
+  if (active) {
+    double prev[3];
+    max_dev = P.max_dev()[g];
+    wpi = P.wp_idx()[g];
+    load_wp(P, g, wpi, cur);
+    load_wp(P, g, wpi - 1, prev);
+    const double p[3] = {S.x, S.y, S.z};
+    des_vel(P, p, cur, dv);
+    dev = deviation(prev, cur, p);
+    if (dev > max_dev) max_dev = dev;
+    rew_k = rvo_reward_k(rvo_reward_pre(dv, a), flag, tmin);
+  }
   __syncthreads();  // everyone is done with the pre-move LDS image
   RVO3D_STAMP(3);
   RVO3D_PRIO(3);
