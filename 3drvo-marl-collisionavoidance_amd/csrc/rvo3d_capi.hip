@@ -50,6 +50,7 @@ struct rvo3d_env {
   void* arena = nullptr;
   size_t arena_bytes = 0;
   bool world_loaded = false;
+  bool dv_valid = false;  // dvk_a/dvk_b describe the current state (see Params::dv_cached)
   int threads = 0, blocks = 0, lds = 0;
 };
 
@@ -303,11 +304,13 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
     HIP_TRY(hipMemcpyAsync((void*)C.bld, buildings, (size_t)C.nb * 32, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(P.extra_len(), 0, EN * 8, s));
   const int tb = 256;
+  hipLaunchKernelGGL(rvo3d::dv0_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P);
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P,
                      (const uint8_t*)nullptr, (const uint8_t*)nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // the host staging vectors die here
   h->world_loaded = true;
+  h->dv_valid = true;  // reset_kernel filed the des_vel of every start state
   return RVO3D_OK;
 }
 
@@ -339,7 +342,9 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   Params P = h->P;
   P.obs = obs; P.vo_count = vo_count;
   P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
-  return launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
+  rc = launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
+  if (rc == RVO3D_OK) h->dv_valid = true;  // observe files the des_vel of every drone
+  return rc;
 }
 
 static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
@@ -356,8 +361,11 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   P.obs = obs; P.vo_count = vo_count; P.reward = reward;
   P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
+  P.dv_cached = h->dv_valid ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  return autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
+  rc = autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
+  if (rc == RVO3D_OK) h->dv_valid = true;  // every step files the des_vel of the state it ends in
+  return rc;
 }
 
 int rvo3d_step(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
@@ -443,6 +451,7 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
                     const uint8_t* dest, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
+  h->dv_valid = false;  // the next step recomputes the pre-move dronestate
   const Params& P = h->P;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int EN = P.E * P.N;

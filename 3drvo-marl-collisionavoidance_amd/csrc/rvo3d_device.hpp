@@ -67,6 +67,7 @@ typedef const __attribute__((address_space(4))) Cold ColdC;
 struct Params {
   int E, N, P, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
+  int dv_cached;      // 1: dvk_a/dvk_b hold des_vel of the current state (skip the pre-move dronestate)
   int action_mode;    // 0: absolute action; 1: policy increment (trainer glue, multi_ppo.py:196-205)
   float acceler;      // ir_gym.acceler as numpy sees it next to a float32 array (float32)
   int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
@@ -83,14 +84,16 @@ struct Params {
   // All per-drone arrays live in one arena, struct-of-arrays with a common element stride
   // S = EN rounded up to 64 (EN = E*N): array k of a block starts at element k*S.  Three base
   // pointers instead of thirty keep the kernel's scalar registers free of spills.
-  //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | route_len radius prio |
-  //        wp [P][3] | row_iet [nm]      i32: wp_idx n_points | row_pk [nm]      u8: arrive dest
+  //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | route_len radius prio dev0 |
+  //        wp [P][3] | row_iet [nm]
+  //   i32: wp_idx n_points | dvk_a dvk_b (des_vel of the current state) | dv0_a dv0_b (of the
+  //        reset state) | row_pk [nm]          u8: arrive dest
   double* f64;
   int32_t* i32;
   uint8_t* u8;
   uint32_t S;
   enum { F_PX, F_PY, F_PZ, F_VX, F_VY, F_VZ, F_YAW, F_PITCH, F_REAL_LEN, F_MAX_DEV, F_EXTRA_LEN,
-         F_ROUTE_LEN, F_RADIUS, F_PRIO, F_WP };
+         F_ROUTE_LEN, F_RADIUS, F_PRIO, F_DEV0, F_WP };
   __host__ __device__ double* f(int k) const { return f64 + (size_t)k * S; }
   // mutable state
   __host__ __device__ double* px() const { return f(F_PX); }
@@ -111,15 +114,23 @@ struct Params {
   __host__ __device__ double* route_len() const { return f(F_ROUTE_LEN); }
   __host__ __device__ double* radius() const { return f(F_RADIUS); }
   __host__ __device__ double* prio() const { return f(F_PRIO); }
+  __host__ __device__ double* dev0() const { return f(F_DEV0); }  // deviation in the reset state
   __host__ __device__ double* wp(int k, int c) const { return f(F_WP + 3 * k + c); }  // [P][3]
   __host__ __device__ int32_t* n_points() const { return i32 + S; }
+  // des_vel = k / 1000 (drone.py:199-210), packed (dv_encode): of the current state, written by
+  // every step / observe (valid unless the state was set from outside: dv_cached), and of the
+  // reset state (static)
+  __host__ __device__ uint32_t* dvk_a() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)2 * S; }
+  __host__ __device__ uint32_t* dvk_b() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)3 * S; }
+  __host__ __device__ uint32_t* dv0_a() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)4 * S; }
+  __host__ __device__ uint32_t* dv0_b() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)5 * S; }
   // kept VO rows of the sweep in flight, [nm] arrays (touched only when a pair is flagged)
   __host__ __device__ double* row_iet(int s) const { return f(F_WP + 3 * P + s); }  // 1/(t+0.2)
   __host__ __device__ uint32_t* row_pk(int s) const {                    // (alpha*100) << 16 | j
-    return reinterpret_cast<uint32_t*>(i32) + (size_t)(2 + s) * S;
+    return reinterpret_cast<uint32_t*>(i32) + (size_t)(6 + s) * S;
   }
   __host__ __device__ static size_t f64_arrays(int P_, int nm_) { return F_WP + 3 * (size_t)P_ + (nm_ > 0 ? nm_ : 1); }
-  __host__ __device__ static size_t i32_arrays(int nm_) { return 2 + (size_t)(nm_ > 0 ? nm_ : 1); }
+  __host__ __device__ static size_t i32_arrays(int nm_) { return 6 + (size_t)(nm_ > 0 ? nm_ : 1); }
   uint32_t* err;
   const Cold* cold_;   // device copy of the rarely used parameters
   __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
@@ -181,6 +192,31 @@ __device__ __forceinline__ double k_over_1000(double k) {
   const double r = __builtin_fma(-q, 1000.0, k);
   const double c = q + r * 0.001;
   return finite_d(k) ? c : k;
+}
+
+// des_vel is k / 1000 with integer |k| <= 1000 (np.round(., 3) of a unit vector, drone.py:210)
+// or 0: three 11-bit fields (k + 1024) and the signs of zeros.  a == ~0u marks "not of that
+// form" (NaN input): the reader recomputes.
+constexpr uint32_t kDvInvalid = 0xffffffffu;
+__device__ __forceinline__ void dv_encode(const double dv[3], uint32_t& a, uint32_t& b) {
+  const double k0 = __builtin_rint(dv[0] * 1000.0), k1 = __builtin_rint(dv[1] * 1000.0),
+               k2 = __builtin_rint(dv[2] * 1000.0);
+  const bool ok = __builtin_fabs(k0) <= 1023.0 && __builtin_fabs(k1) <= 1023.0 &&
+                  __builtin_fabs(k2) <= 1023.0 && k_over_1000(k0) == dv[0] &&
+                  k_over_1000(k1) == dv[1] && k_over_1000(k2) == dv[2];
+  const uint32_t nz = (uint32_t)(k0 == 0.0 && __builtin_signbit(dv[0])) |
+                      ((uint32_t)(k1 == 0.0 && __builtin_signbit(dv[1])) << 1) |
+                      ((uint32_t)(k2 == 0.0 && __builtin_signbit(dv[2])) << 2);
+  a = ok ? ((uint32_t)((int)k0 + 1024) | ((uint32_t)((int)k1 + 1024) << 16)) : kDvInvalid;
+  b = (uint32_t)((int)(ok ? k2 : 0.0) + 1024) | (nz << 16);
+}
+__device__ __forceinline__ bool dv_decode(uint32_t a, uint32_t b, double dv[3]) {
+  if (a == kDvInvalid) return false;
+  const int k0 = (int)(a & 0xffffu) - 1024, k1 = (int)(a >> 16) - 1024, k2 = (int)(b & 0xffffu) - 1024;
+  dv[0] = (b & (1u << 16)) ? -0.0 : k_over_1000((double)k0);
+  dv[1] = (b & (1u << 17)) ? -0.0 : k_over_1000((double)k1);
+  dv[2] = (b & (1u << 18)) ? -0.0 : k_over_1000((double)k2);
+  return true;
 }
 
 // Python round(x, 2): correctly rounded decimal, ties to even (vel_obs3D.py:15).
@@ -662,18 +698,13 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     }
   }
   if (ROWS && !TOUCH) RVO3D_STAMP(12);
+  if (!ROWS) RVO3D_STAMP(14);
   __syncthreads();
   if (active && !(P.ablate & 32)) {
     const int lbase = el * N;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
-#ifdef RVO3D_DIAG_COUNTS
-      if (ROWS && !TOUCH && P.dbg) {
-        atomicMax(&P.dbg[(size_t)blockIdx.x * 16 + 14], (unsigned long long)__builtin_popcountll(m2));
-        atomicAdd(&P.dbg[(size_t)blockIdx.x * 16 + 15], (unsigned long long)__builtin_popcountll(m2));
-      }
-#endif
       while (m2) {  // stage X2: exact, requested pairs only
         const int j = 64 * w + __builtin_ctzll(m2);
         m2 &= m2 - 1;
@@ -688,6 +719,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     }
   }
   if (ROWS && !TOUCH) RVO3D_STAMP(13);
+  if (!ROWS) RVO3D_STAMP(15);
   return kept;
 }
 
@@ -860,10 +892,24 @@ __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid
     const uint32_t cbeg = (uint32_t)((rb * (unsigned)row0 + 15) >> 4);
     const uint32_t cend = (uint32_t)((rb * (unsigned)(row0 + nrows)) >> 4);
     float4* ob = reinterpret_cast<float4*>(P.obs);
-    for (uint32_t c = cbeg + tid; c < cend; c += L.T) {
-      const uint32_t grow = (uint32_t)(((unsigned long long)(2u * c) * P.cold().zf_m40) >> 40);
-      const uint32_t lr = grow - (uint32_t)row0;
-      if (c >= L.zc[2 * lr] && c < L.zc[2 * lr + 1]) ob[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint2* zc2 = reinterpret_cast<const uint2*>(L.zc);
+    const unsigned long long m40 = P.cold().zf_m40;
+    // four chunks per trip: the run lookups (one 8-B LDS read each) are issued together
+    // and nothing in the body branches, so a trip costs one LDS round trip, not eight
+    for (uint32_t c = cbeg + tid; c < cend; c += 4 * L.T) {
+      uint2 z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t cu = c + u * L.T;
+        const uint32_t cc = cu < cend ? cu : c;  // clamp: the lookup stays inside this block
+        const uint32_t grow = (uint32_t)(((unsigned long long)(2u * cc) * m40) >> 40);
+        z[u] = zc2[grow - (uint32_t)row0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t cu = c + u * L.T;
+        if ((cu < cend) & (cu >= z[u].x) & (cu < z[u].y)) ob[cu] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     return;
   }
@@ -1079,6 +1125,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       write_vo_rows(P, L, tid, lbase, g, S, kept);
       L.kept[tid] = kept;
       P.max_dev()[g] = max_dev;
+      uint32_t dvk_a, dvk_b;
+      dv_encode(dv, dvk_a, dvk_b);
+      P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
     }
     __syncthreads();
     zero_fill(P, L, tid, e0 * N, nrows);
@@ -1098,18 +1147,24 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
                               tmin, collision);
-  // drone.dronestate on the pre-move state (drone.py:254-263) and the RVO reward
+  // drone.dronestate on the pre-move state (drone.py:254-263) and the RVO reward.  The state
+  // is the one the previous step (or observe / reset) ended in, so its des_vel is on file and
+  // its deviation is already in max_deviation; only a state set from outside is recomputed.
   double rew_k = 0;
   if (active) {
-    double prev[3];
     max_dev = P.max_dev()[g];
     wpi = P.wp_idx()[g];
     load_wp(P, g, wpi, cur);
-    load_wp(P, g, wpi - 1, prev);
-    const double p[3] = {S.x, S.y, S.z};
-    des_vel(P, p, cur, dv);
-    dev = deviation(prev, cur, p);
-    if (dev > max_dev) max_dev = dev;
+    bool have = false;
+    if (P.dv_cached) have = dv_decode(P.dvk_a()[g], P.dvk_b()[g], dv);
+    if (!have) {
+      double prev[3];
+      load_wp(P, g, wpi - 1, prev);
+      const double p[3] = {S.x, S.y, S.z};
+      des_vel(P, p, cur, dv);
+      dev = deviation(prev, cur, p);
+      if (dev > max_dev) max_dev = dev;
+    }
     rew_k = rvo_reward_k(rvo_reward_pre(dv, a), flag, tmin);
   }
   __syncthreads();  // everyone is done with the pre-move LDS image
@@ -1226,10 +1281,14 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
       double p[3];
       load_wp(P, g, 0, p);
-      load_wp(P, g, 1, cur);
       S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
-      des_vel(P, p, cur, dv);
-      dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
+      // dronestate of the start state: static, tabulated by rvo3d_load_world (dv0_kernel)
+      dev = P.dev0()[g];
+      if (!dv_decode(P.dv0_a()[g], P.dv0_b()[g], dv)) {
+        load_wp(P, g, 1, cur);
+        des_vel(P, p, cur, dv);
+        dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
+      }
       max_dev = dev > 0.0 ? dev : 0.0;
       P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
       P.real_len()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
@@ -1243,6 +1302,11 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // after the last sweep (vector memory returns in order: a load behind a store waits for
   // it), but only the rounded floats of des_vel / deviation stay live across the sweep.
   const ProprioTail ptail = proprio_tail(dv, dev);
+  if (active) {  // file des_vel for the next step (two stores now: nothing to carry)
+    uint32_t dvk_a, dvk_b;
+    dv_encode(dv, dvk_a, dvk_b);
+    P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
+  }
   if (LITE) {
     __syncthreads();
     RVO3D_STAMP(6);
@@ -1287,6 +1351,26 @@ __global__ void reset_kernel(const Params P, const uint8_t* env_mask, const uint
   P.vx()[g] = 0.0; P.vy()[g] = 0.0; P.vz()[g] = 0.0;
   P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
   P.real_len()[g] = 0.0; P.max_dev()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
+  // des_vel of the start state is on file; a start state with a non-zero deviation (only
+  // with non-finite waypoints) is left to the step's own dronestate
+  const bool plain = P.dev0()[g] == 0.0;
+  P.dvk_a()[g] = plain ? P.dv0_a()[g] : kDvInvalid;
+  P.dvk_b()[g] = P.dv0_b()[g];
+}
+
+// rvo3d_load_world: dronestate of every drone's reset state (drone.py:254-263 after
+// drone.reset, :270-291): des_vel towards waypoint 1 and the deviation from the first leg.
+__global__ void dv0_kernel(const Params P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.E * P.N) return;
+  double p[3], cur[3], dv[3];
+  load_wp(P, g, 0, p);
+  load_wp(P, g, 1, cur);
+  des_vel(P, p, cur, dv);
+  uint32_t a, b;
+  dv_encode(dv, a, b);
+  P.dv0_a()[g] = a; P.dv0_b()[g] = b;
+  P.dev0()[g] = deviation(p, cur, p);
 }
 
 __global__ void des_vel_kernel(const Params P, double* out) {

@@ -30,10 +30,8 @@ if s[:, 10:14].any():  # inner stamps of the final sweep (diagnostic builds only
     inner = np.diff(s[:, 10:14], axis=1)
     for i, n in enumerate(["G", "X1", "sync+X2+rows"]):
         print(f"  final sweep {n:14s} {inner[:, i].mean():9.0f} {np.median(inner[:, i]):9.0f} {np.percentile(inner[:, i], 95):9.0f}")
-    print("  X2 requests per lane: max over wave mean", s[:, 14].mean(), "p50", np.median(s[:, 14]), "p95", np.percentile(s[:, 14], 95), "max", s[:, 14].max(),
-          "| sum per wave mean", s[:, 15].mean(), "p95", np.percentile(s[:, 15], 95))
-    print("  corr(wave life, max requests) =", np.corrcoef(life, s[:, 14])[0, 1], " corr(life, sum) =", np.corrcoef(life, s[:, 15])[0, 1])
-    print("  wave life p5/p50/p95/max", np.percentile(life, [5, 50, 95, 100]))
+    print(f"  sweep A: G+X1 {(s[:, 14] - s[:, 2]).mean():8.0f}  X2 {(s[:, 15] - s[:, 14]).mean():8.0f}  "
+          f"dronestate+reward {(s[:, 3] - s[:, 15]).mean():8.0f}")
     print("  final sweep pre-G", (s[:, 10] - s[:, 6]).mean(), "post", (s[:, 7] - s[:, 13]).mean())
 
 # per clock-domain view: s_memtime is not synchronised across XCDs, so cluster the
