@@ -340,6 +340,14 @@ struct Lds {
 
 // floats per fp32 array: two copies of every env of the workgroup
 __host__ __device__ inline int f32_len(int T, int N, int epb) { return (2 * epb * N + 3) & ~3; }
+// One-wave workgroups (NW == 1: T = 64, epb * N <= 64) use fixed array lengths, so every LDS
+// array sits at a compile-time offset from one base (address = base + constant + 4 * index).
+__host__ __device__ inline int f32_len_nw(int T, int N, int epb, int NW) {
+  return NW == 1 ? 128 : f32_len(T, N, epb);
+}
+__host__ __device__ inline int f32_single_nw(int N, int epb, int NW) {
+  return NW == 1 ? 64 : ((epb * N + 3) & ~3);
+}
 
 __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int epb, int N,
                                          int NW) {
@@ -351,7 +359,7 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
   L.kept = reinterpret_cast<int*>(L.mask2 + (size_t)T * NW);
   L.zc = reinterpret_cast<uint32_t*>(L.kept + T);
   float* wf = reinterpret_cast<float*>(L.zc + 2 * T);
-  const int FL = f32_len(T, N, epb), FS = (epb * N + 3) & ~3;
+  const int FL = f32_len_nw(T, N, epb, NW), FS = f32_single_nw(N, epb, NW);
   // order: WX WY WZ WR doubled, then the single-copy arrays
   L.w[0] = wf; L.w[1] = wf + FL; L.w[2] = wf + 2 * FL; L.w[6] = wf + 3 * FL;
   float* ws = wf + 4 * (size_t)FL;
@@ -365,7 +373,8 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
 __host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, int N, int NW) {
   (void)nm;
   return (size_t)T * 8 * 8 + (size_t)T * NW * 8 + (size_t)T * 12 +
-         (size_t)f32_len(T, N, epb) * 16 + (size_t)((epb * N + 3) & ~3) * 32 + (size_t)epb * 8 + 16;
+         (size_t)f32_len_nw(T, N, epb, NW) * 16 + (size_t)f32_single_nw(N, epb, NW) * 32 +
+         (size_t)epb * 8 + 16;
 }
 
 __device__ __forceinline__ Drone lds_drone(const Lds& L, int k) {
@@ -1020,7 +1029,7 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 template <int MODE, int NW>
 __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, T = blockDim.x, N = P.N;
+  const int tid = threadIdx.x, T = NW == 1 ? 64 : (int)blockDim.x, N = P.N;
   const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
   const int el = tid / N;
   const int d = tid - el * N;

@@ -5,7 +5,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "3drvo-marl-collisionavoidance_amd"))
 from rvo3d_amd import BatchedDroneEnv, synthetic_actions, synthetic_world, _lib
-E, N = 4096, 64
+E, N = int(os.environ.get("STAMPS_E", 4096)), 64
 env = BatchedDroneEnv(synthetic_world(E, N, (50, 50, 10)), action_decimals=2)
 acts = [torch.from_numpy(synthetic_actions(E, N, t).astype(np.float32)).cuda() for t in range(12)]
 env.observe()
