@@ -51,6 +51,7 @@ struct rvo3d_env {
   size_t arena_bytes = 0;
   bool world_loaded = false;
   bool dv_valid = false;  // dvk_a/dvk_b describe the current state (see Params::dv_cached)
+  bool g_valid = false;   // gcache describes the current state (see Params::g_cached)
   int threads = 0, blocks = 0, lds = 0;
 };
 
@@ -65,7 +66,7 @@ int carve(rvo3d_env* h) {
   rvo3d::Cold& C = h->cold;
   P.S = (uint32_t)S;
   const size_t nf = Params::f64_arrays(c.max_points, c.neighbors_num);
-  const size_t ni = Params::i32_arrays(c.neighbors_num);
+  const size_t ni = Params::i32_arrays(c.neighbors_num, P.nw);
   struct Field { void** slot; size_t bytes; };
   std::vector<Field> f = {
       {(void**)&P.f64, nf * S * 8},
@@ -311,6 +312,7 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   HIP_TRY(hipStreamSynchronize(s));  // the host staging vectors die here
   h->world_loaded = true;
   h->dv_valid = true;  // reset_kernel filed the des_vel of every start state
+  h->g_valid = false;
   return RVO3D_OK;
 }
 
@@ -318,6 +320,7 @@ int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
   const size_t EN = (size_t)h->P.E * h->P.N;
+  h->g_valid = false;  // positions change: the stage-G words on file are stale
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), h->P, env_mask, (const uint8_t*)nullptr);
   HIP_TRY(hipGetLastError());
@@ -329,6 +332,7 @@ int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
   if (rc) return rc;
   if (!drone_mask) return fail(RVO3D_ERR_INVALID, "drone_mask is required");
   const size_t EN = (size_t)h->P.E * h->P.N;
+  h->g_valid = false;
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), h->P, (const uint8_t*)nullptr, drone_mask);
   HIP_TRY(hipGetLastError());
@@ -343,7 +347,7 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   P.obs = obs; P.vo_count = vo_count;
   P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   rc = launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
-  if (rc == RVO3D_OK) h->dv_valid = true;  // observe files the des_vel of every drone
+  if (rc == RVO3D_OK) h->dv_valid = h->g_valid = true;  // observe files des_vel and the stage-G words
   return rc;
 }
 
@@ -362,9 +366,10 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   P.zf16 = (h->cold.zf_q != 0 && (reinterpret_cast<uintptr_t>(obs) & 15) == 0 && P.nm > 0) ? 1 : 0;
   P.done = done; P.info = info; P.finish = finish; P.reset_mask = reset_mask;
   P.dv_cached = h->dv_valid ? 1 : 0;
+  P.g_cached = h->g_valid ? 1 : 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   rc = autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
-  if (rc == RVO3D_OK) h->dv_valid = true;  // every step files the des_vel of the state it ends in
+  if (rc == RVO3D_OK) h->dv_valid = h->g_valid = true;  // every step files both for the state it ends in
   return rc;
 }
 
@@ -451,7 +456,7 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
                     const uint8_t* dest, void* stream) {
   int rc = check(h, true);
   if (rc) return rc;
-  h->dv_valid = false;  // the next step recomputes the pre-move dronestate
+  h->dv_valid = h->g_valid = false;  // the next step recomputes the pre-move dronestate and stage G
   const Params& P = h->P;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int EN = P.E * P.N;

@@ -68,6 +68,7 @@ struct Params {
   int E, N, P, nm, env_train, epb, W;
   int action_f64;     // 1: actions are double
   int dv_cached;      // 1: dvk_a/dvk_b hold des_vel of the current state (skip the pre-move dronestate)
+  int g_cached;       // 1: gcache holds the in-range words (stage G) of the current state
   int action_mode;    // 0: absolute action; 1: policy increment (trainer glue, multi_ppo.py:196-205)
   float acceler;      // ir_gym.acceler as numpy sees it next to a float32 array (float32)
   int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
@@ -87,7 +88,8 @@ struct Params {
   //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | route_len radius prio dev0 |
   //        wp [P][3] | row_iet [nm]
   //   i32: wp_idx n_points | dvk_a dvk_b (des_vel of the current state) | dv0_a dv0_b (of the
-  //        reset state) | row_pk [nm]          u8: arrive dest
+  //        reset state) | gcache [nw] (stage-G words of the current state) | row_pk [nm]
+  //   u8:  arrive dest
   double* f64;
   int32_t* i32;
   uint8_t* u8;
@@ -124,13 +126,17 @@ struct Params {
   __host__ __device__ uint32_t* dvk_b() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)3 * S; }
   __host__ __device__ uint32_t* dv0_a() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)4 * S; }
   __host__ __device__ uint32_t* dv0_b() const { return reinterpret_cast<uint32_t*>(i32) + (size_t)5 * S; }
+  // stage-G result of the sweep that ended the last step / observe: word w of drone g has bit b
+  // set when neighbour d + 32w + b + 1 is possibly within 10 m.  The next step's sweep A runs
+  // on the same state and starts from it (g_cached).
+  __host__ __device__ uint32_t* gcache(int w) const { return reinterpret_cast<uint32_t*>(i32) + (size_t)(6 + w) * S; }
   // kept VO rows of the sweep in flight, [nm] arrays (touched only when a pair is flagged)
   __host__ __device__ double* row_iet(int s) const { return f(F_WP + 3 * P + s); }  // 1/(t+0.2)
   __host__ __device__ uint32_t* row_pk(int s) const {                    // (alpha*100) << 16 | j
-    return reinterpret_cast<uint32_t*>(i32) + (size_t)(6 + s) * S;
+    return reinterpret_cast<uint32_t*>(i32) + (size_t)(6 + nw + s) * S;
   }
   __host__ __device__ static size_t f64_arrays(int P_, int nm_) { return F_WP + 3 * (size_t)P_ + (nm_ > 0 ? nm_ : 1); }
-  __host__ __device__ static size_t i32_arrays(int nm_) { return 6 + (size_t)(nm_ > 0 ? nm_ : 1); }
+  __host__ __device__ static size_t i32_arrays(int nm_, int nw_) { return 6 + (size_t)nw_ + (size_t)(nm_ > 0 ? nm_ : 1); }
   uint32_t* err;
   const Cold* cold_;   // device copy of the rarely used parameters
   __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
@@ -582,7 +588,7 @@ template <int NW, bool ROWS, bool TOUCH>
 __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
                                          int g, bool active, const Drone& S, const double a[3],
                                          bool zero_act, bool& flag, double& tmin,
-                                         bool& collision) {
+                                         bool& collision, uint32_t gw[NW], bool have_gw) {
   flag = false;
   tmin = __builtin_inf();
   int kept = 0;
@@ -604,8 +610,13 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       if (ROWS && !TOUCH) RVO3D_STAMP(10);
-      uint32_t cand = far ? valid[w]
-                          : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+      // stage G, unless the words of this very state are on file (gw in, have_gw)
+      uint32_t cand;
+      if (have_gw) cand = gw[w];
+      else {
+        cand = far ? valid[w] : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+        gw[w] = cand;
+      }
       if (P.ablate & 64) cand = 0;
       if (ROWS && !TOUCH) RVO3D_STAMP(11);
       // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd
@@ -1127,8 +1138,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       dev = deviation(prev, cur, p);
       if (dev > max_dev) max_dev = dev;
     }
+    uint32_t gw[NW];
     const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
-                                               tmin, collision);
+                                               tmin, collision, gw, false);
     if (active) {
       write_proprio(P, g, S, proprio_tail(dv, dev));
       write_vo_rows(P, L, tid, lbase, g, S, kept);
@@ -1137,6 +1149,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       uint32_t dvk_a, dvk_b;
       dv_encode(dv, dvk_a, dvk_b);
       P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     }
     __syncthreads();
     zero_fill(P, L, tid, e0 * N, nrows);
@@ -1154,8 +1168,14 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   RVO3D_STAMP(2);
   RVO3D_PRIO(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
+  uint32_t gw[NW];
+  const bool have_gw = P.g_cached != 0;  // the previous step ended in this very state
+  if (have_gw && active) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
+  }
   sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
-                              tmin, collision);
+                              tmin, collision, gw, have_gw);
   // drone.dronestate on the pre-move state (drone.py:254-263) and the RVO reward.  The state
   // is the one the previous step (or observe / reset) ended in, so its des_vel is on file and
   // its deviation is already in max_deviation; only a state set from outside is recomputed.
@@ -1272,7 +1292,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
   } else {
     kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
-                                     flag, tmin, collision);
+                                     flag, tmin, collision, gw, false);
   }
   bool do_reset = false;
   if (active) {
@@ -1326,7 +1346,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     bool c2 = false;
     const double* aa = env_reset ? zero3 : az;
     kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
-                                      env_reset, flag, tmin, c2);
+                                      env_reset, flag, tmin, c2, gw, false);
   }
   RVO3D_STAMP(7);
   RVO3D_PRIO(7);
@@ -1337,6 +1357,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     }
     L.kept[tid] = kept;
     P.max_dev()[g] = max_dev;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     P.px()[g] = S.x; P.py()[g] = S.y; P.pz()[g] = S.z;
     P.vx()[g] = S.vx; P.vy()[g] = S.vy; P.vz()[g] = S.vz;
   }
