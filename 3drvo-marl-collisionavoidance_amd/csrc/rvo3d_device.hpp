@@ -548,11 +548,12 @@ __device__ __forceinline__ void valid_offsets(int N, int d, uint32_t valid[NW]) 
 // (and in range); else: possibly in range.
 template <bool TOUCHONLY>
 __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int o0, int w, int H,
-                                              float mex, float mey, float mez, float mer) {
+                                              float mex, float mey, float mez, float mer,
+                                              uint32_t* range_out = nullptr) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
   const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
-  uint32_t m = 0u;
+  uint32_t m = 0u, mr = 0u;
 #pragma unroll 8
   for (int b = 0; b < kend; b += 2) {
     const int o = o0 + 32 * w + b + 1;
@@ -564,6 +565,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
     d2 = __builtin_elementwise_fma(dz, dz, d2);
     uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
     if (TOUCHONLY) {
+      if (range_out) mr |= (b0 | (b1 << 1)) << b;  // the in-range word on the side
       const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
       const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
                                                (v2f){P.band, P.band});
@@ -572,6 +574,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
     }
     m |= (b0 | (b1 << 1)) << b;
   }
+  if (TOUCHONLY && range_out) *range_out = mr;
   return m;
 }
 
@@ -750,7 +753,8 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 // touching, the decision itself is fp64.
 template <int NW>
 __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int lane, int el,
-                                            int d, bool active, const Drone& S) {
+                                            int d, bool active, const Drone& S,
+                                            uint32_t gw[NW]) {
   const int N = P.N, H = N >> 1;
   L.mask2[lane * NW] = 0ull;
   __syncthreads();
@@ -763,8 +767,15 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
     valid_offsets<NW>(N, d, valid);
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      uint32_t cand = far ? valid[w]
-                          : (gate_word<true>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+      // one pass over the offsets: possibly touching (cand) and possibly in range (gw, the
+      // stage-G words of this post-move state for the rows sweep that follows)
+      uint32_t cand = valid[w];
+      gw[w] = valid[w];
+      if (!far) {
+        uint32_t rng;
+        cand = gate_word<true>(P, L, o0, w, H, mex, mey, mez, mer, &rng) & valid[w];
+        gw[w] = rng & valid[w];
+      }
       while (cand) {  // exact decision, both drones of the pair
         const int kb = __builtin_ctz(cand);
         cand &= cand - 1;
@@ -792,6 +803,54 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
   __syncthreads();
   if (active && (L.mask2[lane * NW] & 1ull)) coll = true;
   return coll;
+}
+
+// One-wave workgroups: bring the stage-G word of every drone up to date after the drones in
+// `reset_lanes` (ballot) moved to their start positions (fp32 image already restaged).  Only
+// pairs with a reset drone change: each reset drone r is tested against all lanes of its env
+// at once (same arithmetic as gate_word, so the bits equal a full recomputation); the pair's
+// owner - the end whose offset to the other is <= N/2 - takes the bit, and r itself rebuilds
+// its word from the ballot rotated to its own offset order.
+__device__ __forceinline__ uint32_t regate_resets(const Params& P, const Lds& L, int tid, int el,
+                                                  int d, bool active,
+                                                  unsigned long long reset_lanes, uint32_t gw) {
+  const int N = P.N, H = N >> 1;
+  uint32_t valid[1];
+  valid_offsets<1>(N, d, valid);
+  const int o0 = el * 2 * N + d;
+  const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
+  while (reset_lanes) {
+    const int rl = __builtin_ctzll(reset_lanes);
+    reset_lanes &= reset_lanes - 1;
+    const int rel = __builtin_amdgcn_readlane(el, rl), rd = __builtin_amdgcn_readlane(d, rl);
+    const int orr = rel * 2 * N + rd;
+    const float dx = L.w[WX][orr] - mex, dy = L.w[WY][orr] - mey, dz = L.w[WZ][orr] - mez;
+    float d2 = dx * dx;
+    d2 = __builtin_fmaf(dy, dy, d2);
+    d2 = __builtin_fmaf(dz, dz, d2);
+    const bool same = active && el == rel && tid != rl;
+    const bool inr = same && d2 <= P.t10f;
+    int k = rd - d;  // offset from me to r
+    if (k < 0) k += N;
+    if (same && k >= 1 && k <= H) {  // I own the pair (if the offset is mine at all)
+      const uint32_t bit = 1u << (k - 1);
+      gw = (gw & ~bit) | ((inr ? bit : 0u) & valid[0]);
+    }
+    const unsigned long long bal = __ballot(inr);
+    if (tid == rl) {
+      unsigned long long seg = bal >> (rel * N), rot;
+      if (N == 64) {
+        const int sh = (rd + 1) & 63;
+        rot = sh ? ((seg >> sh) | (seg << (64 - sh))) : seg;
+      } else {
+        seg &= (1ull << N) - 1ull;
+        const int sh = rd + 1;  // 1..N
+        rot = ((seg >> sh) | (seg << (N - sh))) & ((1ull << N) - 1ull);
+      }
+      gw = (uint32_t)rot & valid[0];
+    }
+  }
+  return gw;
 }
 
 // building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
@@ -1289,7 +1348,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // state with the action, or on the post-reset state with action 0.
   int kept = 0;
   if (LITE) {
-    if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S)) collision = true;
+    if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S, gw)) collision = true;
   } else {
     kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
                                      flag, tmin, collision, gw, false);
@@ -1345,8 +1404,23 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     const bool env_reset = active && (L.any_reset[el] != 0);
     bool c2 = false;
     const double* aa = env_reset ? zero3 : az;
+    // stage G: the collision sweep delivered the words of the post-move state; only pairs
+    // with a reset drone changed since (larger envs: recompute when the env reset anyone)
+    bool have_gw2 = !env_reset;
+    if (NW == 1) {
+      const unsigned long long rlanes = __ballot(do_reset);
+      if (L.far[el] != 0) {
+        uint32_t valid[1];
+        valid_offsets<1>(N, d, valid);
+        gw[0] = valid[0];
+      } else {
+        gw[0] = regate_resets(P, L, tid, el, d, active, rlanes, gw[0]);
+      }
+      have_gw2 = true;
+    }
+    if (P.ablate & 2) have_gw2 = false;  // diagnostics: the collision sweep was skipped
     kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
-                                      env_reset, flag, tmin, c2, gw, false);
+                                      env_reset, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);
   RVO3D_PRIO(7);
