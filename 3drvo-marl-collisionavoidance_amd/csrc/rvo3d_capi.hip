@@ -308,6 +308,7 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   hipLaunchKernelGGL(rvo3d::dv0_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P);
   hipLaunchKernelGGL(rvo3d::reset_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P,
                      (const uint8_t*)nullptr, (const uint8_t*)nullptr);
+  hipLaunchKernelGGL(rvo3d::wpcache_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));  // the host staging vectors die here
   h->world_loaded = true;
@@ -470,7 +471,10 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
   if (real_len) HIP_TRY(hipMemcpyAsync(P.real_len(), real_len, (size_t)EN * 8, k, s));
   if (max_dev) HIP_TRY(hipMemcpyAsync(P.max_dev(), max_dev, (size_t)EN * 8, k, s));
   if (extra_len) HIP_TRY(hipMemcpyAsync(P.extra_len(), extra_len, (size_t)EN * 8, k, s));
-  if (wp_idx) HIP_TRY(hipMemcpyAsync(P.wp_idx(), wp_idx, (size_t)EN * 4, k, s));
+  if (wp_idx) {  // current / previous waypoint follow the index
+    HIP_TRY(hipMemcpyAsync(P.wp_idx(), wp_idx, (size_t)EN * 4, k, s));
+    hipLaunchKernelGGL(rvo3d::wpcache_kernel, grid, blk, 0, s, P);
+  }
   if (arrive) HIP_TRY(hipMemcpyAsync(P.arrive(), arrive, (size_t)EN, k, s));
   if (dest) HIP_TRY(hipMemcpyAsync(P.dest(), dest, (size_t)EN, k, s));
   return RVO3D_OK;

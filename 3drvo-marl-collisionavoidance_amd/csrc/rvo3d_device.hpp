@@ -85,8 +85,9 @@ struct Params {
   // All per-drone arrays live in one arena, struct-of-arrays with a common element stride
   // S = EN rounded up to 64 (EN = E*N): array k of a block starts at element k*S.  Three base
   // pointers instead of thirty keep the kernel's scalar registers free of spills.
-  //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | route_len radius prio dev0 |
-  //        wp [P][3] | row_iet [nm]
+  //   f64: px py pz vx vy vz yaw pitch real_len max_dev extra_len | cur[3] prev[3] (the
+  //        waypoints wp[i], wp[i-1] of the drone's waypoint index i) |
+  //        route_len radius prio dev0 | wp [P][3] | row_iet [nm]
   //   i32: wp_idx n_points | dvk_a dvk_b (des_vel of the current state) | dv0_a dv0_b (of the
   //        reset state) | gcache [nw] (stage-G words of the current state) | row_pk [nm]
   //   u8:  arrive dest
@@ -95,7 +96,8 @@ struct Params {
   uint8_t* u8;
   uint32_t S;
   enum { F_PX, F_PY, F_PZ, F_VX, F_VY, F_VZ, F_YAW, F_PITCH, F_REAL_LEN, F_MAX_DEV, F_EXTRA_LEN,
-         F_ROUTE_LEN, F_RADIUS, F_PRIO, F_DEV0, F_WP };
+         F_CUR, F_PREV = F_CUR + 3,
+         F_ROUTE_LEN = F_PREV + 3, F_RADIUS, F_PRIO, F_DEV0, F_WP };
   __host__ __device__ double* f(int k) const { return f64 + (size_t)k * S; }
   // mutable state
   __host__ __device__ double* px() const { return f(F_PX); }
@@ -118,6 +120,10 @@ struct Params {
   __host__ __device__ double* prio() const { return f(F_PRIO); }
   __host__ __device__ double* dev0() const { return f(F_DEV0); }  // deviation in the reset state
   __host__ __device__ double* wp(int k, int c) const { return f(F_WP + 3 * k + c); }  // [P][3]
+  // drone.current_des / previous_des (drone.py:24-30, 172-192), kept next to the state so
+  // that no load has to wait for the waypoint index
+  __host__ __device__ double* cur(int c) const { return f(F_CUR + c); }
+  __host__ __device__ double* prev(int c) const { return f(F_PREV + c); }
   __host__ __device__ int32_t* n_points() const { return i32 + S; }
   // des_vel = k / 1000 (drone.py:199-210), packed (dv_encode): of the current state, written by
   // every step / observe (valid unless the state was set from outside: dv_cached), and of the
@@ -1019,6 +1025,19 @@ __device__ __forceinline__ void load_wp(const Params& P, int g, int k, double ou
   out[2] = P.wp(k, 2)[g];
 }
 
+__device__ __forceinline__ void load3(double* const a0, double* const a1, double* const a2, int g,
+                                      double out[3]) {
+  out[0] = a0[g]; out[1] = a1[g]; out[2] = a2[g];
+}
+__device__ __forceinline__ void store3(double* const a0, double* const a1, double* const a2, int g,
+                                       const double v[3]) {
+  a0[g] = v[0]; a1[g] = v[1]; a2[g] = v[2];
+}
+#define RVO3D_LOAD_CUR(P, g, out) load3((P).cur(0), (P).cur(1), (P).cur(2), g, out)
+#define RVO3D_LOAD_PREV(P, g, out) load3((P).prev(0), (P).prev(1), (P).prev(2), g, out)
+#define RVO3D_STORE_CUR(P, g, v) store3((P).cur(0), (P).cur(1), (P).cur(2), g, v)
+#define RVO3D_STORE_PREV(P, g, v) store3((P).prev(0), (P).prev(1), (P).prev(2), g, v)
+
 // ir_gym.rvo_reward_cal (ir_gym.py:64-133), the part that does not depend on the sweep:
 // angle_punish + vel_penalty.  The sweep's safety term is added afterwards in the
 // reference's order, (punish + vel_penalty) + safety: rvo_reward_k().
@@ -1189,9 +1208,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (active) {  // drone.dronestate (drone.py:254-263)
       double prev[3];
       max_dev = P.max_dev()[g];
-      wpi = P.wp_idx()[g];
-      load_wp(P, g, wpi, cur);
-      load_wp(P, g, wpi - 1, prev);
+      RVO3D_LOAD_CUR(P, g, cur);
+      RVO3D_LOAD_PREV(P, g, prev);
       const double p[3] = {S.x, S.y, S.z};
       des_vel(P, p, cur, dv);
       dev = deviation(prev, cur, p);
@@ -1235,19 +1253,26 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
                               tmin, collision, gw, have_gw);
-  // drone.dronestate on the pre-move state (drone.py:254-263) and the RVO reward.  The state
-  // is the one the previous step (or observe / reset) ended in, so its des_vel is on file and
-  // its deviation is already in max_deviation; only a state set from outside is recomputed.
+  // ---- everything else about this drone arrives in ONE batch of loads now (none of the
+  //      addresses depends on a loaded value), then: drone.dronestate on the pre-move state
+  //      (drone.py:254-263) and the RVO reward - the state is the one the previous step (or
+  //      observe / reset) ended in, so its des_vel is on file and its deviation is already in
+  //      max_deviation; only a state set from outside is recomputed - and
+  //      drone.move_forward + kinematicstep (drone.py:96-129, 435-490), the post-move
+  //      dronestate and the arrival flags of ir_gym.observation_reward (:168-193)
   double rew_k = 0;
+  double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
+  bool f_dest = false;
+  RVO3D_STAMP(3);
+  RVO3D_PRIO(3);
   if (active) {
     max_dev = P.max_dev()[g];
-    wpi = P.wp_idx()[g];
-    load_wp(P, g, wpi, cur);
+    RVO3D_LOAD_CUR(P, g, cur);
     bool have = false;
     if (P.dv_cached) have = dv_decode(P.dvk_a()[g], P.dvk_b()[g], dv);
     if (!have) {
       double prev[3];
-      load_wp(P, g, wpi - 1, prev);
+      RVO3D_LOAD_PREV(P, g, prev);
       const double p[3] = {S.x, S.y, S.z};
       des_vel(P, p, cur, dv);
       dev = deviation(prev, cur, p);
@@ -1256,23 +1281,16 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     rew_k = rvo_reward_k(rvo_reward_pre(dv, a), flag, tmin);
   }
   __syncthreads();  // everyone is done with the pre-move LDS image
-  RVO3D_STAMP(3);
-  RVO3D_PRIO(3);
-
-  // ---- integrate: drone.move_forward + kinematicstep (drone.py:96-129, 435-490), the
-  //      post-move dronestate and the arrival flags of ir_gym.observation_reward (:168-193)
-  double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
-  bool f_dest = false;
   if (active) {
+    double prev[3];
+    wpi = P.wp_idx()[g];
+    RVO3D_LOAD_PREV(P, g, prev);
     double yaw = P.yaw()[g], pitch = P.pitch()[g], real_len = P.real_len()[g];
     double extra_len = P.extra_len()[g];
     const double route_len = P.route_len()[g];
     const int npts = P.n_points()[g];
     bool f_arrive = P.arrive()[g] != 0;
     f_dest = P.dest()[g] != 0;
-    double dst[3], prev[3];
-    load_wp(P, g, npts - 1, dst);
-    load_wp(P, g, wpi - 1, prev);
 
     double speed = norm3b(S.vx, S.vy, S.vz);
     const double acc = clampd(a[0] * 1.0, -1.0, 1.0);
@@ -1294,6 +1312,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     S.vx = nvx; S.vy = nvy; S.vz = nvz;
     real_len = real_len + norm3b(S.x - q0, S.y - q1, S.z - q2);
     const double p[3] = {S.x, S.y, S.z};
+    // the destination matters only next to a waypoint: fetched on demand (rare)
+    double dst[3] = {0, 0, 0};
+    if (f_arrive || arrived(P, p, cur)) load_wp(P, g, npts - 1, dst);
     if (arrived(P, p, cur)) {  // drone.py:116-129
       const bool at_dst = arrived(P, p, dst);
       if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
@@ -1301,6 +1322,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
         wpi += 1;
         prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
         load_wp(P, g, wpi, cur);
+        RVO3D_STORE_CUR(P, g, cur);
+        RVO3D_STORE_PREV(P, g, prev);
         f_arrive = false;
       }
     }
@@ -1372,11 +1395,13 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
       // dronestate of the start state: static, tabulated by rvo3d_load_world (dv0_kernel)
       dev = P.dev0()[g];
+      load_wp(P, g, 1, cur);
       if (!dv_decode(P.dv0_a()[g], P.dv0_b()[g], dv)) {
-        load_wp(P, g, 1, cur);
         des_vel(P, p, cur, dv);
         dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
       }
+      RVO3D_STORE_CUR(P, g, cur);
+      RVO3D_STORE_PREV(P, g, p);
       max_dev = dev > 0.0 ? dev : 0.0;
       P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
       P.real_len()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
@@ -1456,11 +1481,29 @@ __global__ void reset_kernel(const Params P, const uint8_t* env_mask, const uint
   P.vx()[g] = 0.0; P.vy()[g] = 0.0; P.vz()[g] = 0.0;
   P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
   P.real_len()[g] = 0.0; P.max_dev()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
+  double c1[3];
+  load_wp(P, g, 1, c1);
+  RVO3D_STORE_CUR(P, g, c1);
+  RVO3D_STORE_PREV(P, g, s);
   // des_vel of the start state is on file; a start state with a non-zero deviation (only
   // with non-finite waypoints) is left to the step's own dronestate
   const bool plain = P.dev0()[g] == 0.0;
   P.dvk_a()[g] = plain ? P.dv0_a()[g] : kDvInvalid;
   P.dvk_b()[g] = P.dv0_b()[g];
+}
+
+// cur / prev from the waypoint index (rvo3d_load_world; rvo3d_set_state with wp_idx)
+__global__ void wpcache_kernel(const Params P) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= P.E * P.N) return;
+  const int np = P.n_points()[g];
+  int i = P.wp_idx()[g];
+  i = i < 1 ? 1 : (i > np - 1 ? np - 1 : i);  // the clamp only guards the table lookup
+  double v[3];
+  load_wp(P, g, i, v);
+  RVO3D_STORE_CUR(P, g, v);
+  load_wp(P, g, i - 1, v);
+  RVO3D_STORE_PREV(P, g, v);
 }
 
 // rvo3d_load_world: dronestate of every drone's reset state (drone.py:254-263 after
@@ -1482,7 +1525,7 @@ __global__ void des_vel_kernel(const Params P, double* out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= P.E * P.N) return;
   double p[3] = {P.px()[g], P.py()[g], P.pz()[g]}, cur[3], dv[3];
-  load_wp(P, g, P.wp_idx()[g], cur);
+  RVO3D_LOAD_CUR(P, g, cur);
   des_vel(P, p, cur, dv);
   out[3 * (size_t)g] = dv[0]; out[3 * (size_t)g + 1] = dv[1]; out[3 * (size_t)g + 2] = dv[2];
 }
