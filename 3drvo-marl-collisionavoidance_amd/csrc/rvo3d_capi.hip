@@ -159,8 +159,6 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   C.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
   P.W = 12 + 9 * P.nm;
   if (const char* ab = std::getenv("RVO3D_ABLATE")) P.ablate = std::atoi(ab);  // diagnostics only
-  if (const char* sg = std::getenv("RVO3D_STAGGER")) C.stagger = std::atoi(sg);
-  if (const char* sp = std::getenv("RVO3D_STAGGER_PRIO")) C.stagger_prio = std::atoi(sp);
   C.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
   for (int k = 0; k < 3; ++k) C.map[k] = cfg->map_size[k];
   P.T10 = sq_threshold(10.0);  // rvo_inter.py:96

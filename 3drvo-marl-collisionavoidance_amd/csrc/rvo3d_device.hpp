@@ -57,8 +57,6 @@ struct Cold {
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
   uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
   int nb;
-  int stagger;        // diagnostics: wave slot s of a SIMD starts s * stagger * 64 cycles late
-  int stagger_prio;   // diagnostics: issue priority per wave slot
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
 };
@@ -160,20 +158,6 @@ struct Params {
 #define RVO3D_STAMP(i)                                                                  \
   do {                                                                                  \
     if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-
-// issue priority of this wave (s_setprio takes an immediate)
-__device__ __forceinline__ void set_prio(unsigned p) {
-  if (p == 0) __builtin_amdgcn_s_setprio(0);
-  else if (p == 1) __builtin_amdgcn_s_setprio(1);
-  else if (p == 2) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(3);
-}
-// stagger_prio 2: rotate the priority of the waves of a SIMD at every phase boundary
-#define RVO3D_PRIO(phase)                                                     \
-  do {                                                                        \
-    if (P.cold().stagger_prio == 2) set_prio((wslot + (unsigned)(phase)) & 3u);      \
-    else if (P.cold().stagger_prio == 4) set_prio((wslot + ((unsigned)(phase) >> 1)) & 3u); \
   } while (0)
 
 // ---- arithmetic primitives -------------------------------------------------
@@ -676,7 +660,9 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
         const v2f sq_ = {__builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.x, 0.f)),
                          __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.y, 0.f))};
-        const v2f K = (v2f){0.999998f, 0.999998f} * sq_ - (v2f){2.0e-3f, 2.0e-3f} * rs;
+        // K <= 0: the second clause below is empty (its bound becomes 0)
+        const v2f Kr = (v2f){0.999998f, 0.999998f} * sq_ - (v2f){2.0e-3f, 2.0e-3f} * rs;
+        const v2f K = {__builtin_fmaxf(Kr.x, 0.f), __builtin_fmaxf(Kr.y, 0.f)};
         const v2f K2 = K * K * (v2f){P.x1_k2, P.x1_k2};
         const v2f hf = {0.5f, 0.5f};
         const v2f hx = hf * (mvx2 + jvx), hy = hf * (mvy2 + jvy), hz = hf * (mvz2 + jvz);
@@ -694,19 +680,18 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         const v2f wj2 = __builtin_elementwise_fma(
             wjz, wjz, __builtin_elementwise_fma(wjy, wjy, wjx * wjx));
         const v2f cs = (v2f){P.x1_cs2, P.x1_cs2} * d2;
-        const v2f dpi2 = dpi * dpi, dpj2 = dpj * dpj;
-        const v2f ci = cs * wi2, cj = cs * wj2, ki = wi2 * K2, kj = wj2 * K2;
-        // surely outside: cos < -cs, or 0 <= cos < cos(alpha + delta) with slack
+        // signed squares: s = dp |dp|.  Surely outside the cone: cos < -cs (s < -cs w2), or
+        // 0 <= cos < cos(alpha + delta) with slack (0 <= s < K^2 w2); one bound per sign of s
+        // and ONE comparison s < bound (a NaN compares false: the pair is kept).
+        const v2f si = dpi * __builtin_elementwise_abs(dpi), sj = dpj * __builtin_elementwise_abs(dpj);
+        const v2f ci = -(cs * wi2), cj = -(cs * wj2), ki = wi2 * K2, kj = wj2 * K2;
 #define RVO3D_X1_HALF(c, jd, pi, pj)                                                          \
         {                                                                                     \
           const int touch = TOUCH & (int)(d2.c <= tch.c);                                     \
           const int ai = vi.c > -mkd, aj = vj.c < jkd.c;                                      \
           const int filt = (int)(gap.c >= P.x1_gap) & (int)(jprio.c == mprio);                \
-          const int kpos = K.c > 0.f;                                                         \
-          const int oi = ((int)(dpi.c < 0.f) & (int)(dpi2.c > ci.c)) |                        \
-                         ((int)(dpi.c >= 0.f) & kpos & (int)(dpi2.c < ki.c));                 \
-          const int oj = ((int)(dpj.c < 0.f) & (int)(dpj2.c > cj.c)) |                        \
-                         ((int)(dpj.c >= 0.f) & kpos & (int)(dpj2.c < kj.c));                 \
+          const int oi = si.c < (si.c < 0.f ? ci.c : ki.c);                                   \
+          const int oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                   \
           pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
           pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
         }
@@ -916,8 +901,7 @@ __device__ __forceinline__ void write_proprio(const Params& P, int g, const Dron
 // iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
 // behind them (written by zero_fill()).
 __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int tid, int lbase,
-                                              int g, const Drone& S, int kept,
-                                              bool prezeroed = false) {
+                                              int g, const Drone& S, int kept) {
   float* o = P.obs + (size_t)g * P.W;
   bool bad = false;
   for (int s = 0; s < kept; ++s) {
@@ -938,11 +922,6 @@ __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int
       bad |= !finite_d(row[k]);
       o[12 + 9 * s + k] = round2_f32(row[k]);
     }
-  }
-  if (prezeroed) {  // the whole VO region was zeroed at the start of the step
-    P.vo_count[g] = kept;
-    if (bad) atomicOr(P.err, 1u);
-    return;
   }
   // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
   if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
@@ -1134,14 +1113,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // stored as soon as they are final, so that across the sweeps little more than the
   // drone's own 8-value record and its action stay live (registers = waves per SIMD).
   RVO3D_STAMP(0);
-  // HW_REG_HW_ID (id 4) bits [3:0] = wave slot on its SIMD.  The SIMD issues oldest-first, so
-  // the waves of a one-round grid finish one after the other and the last one runs alone;
-  // per-slot priorities (diagnostics: RVO3D_STAGGER_PRIO) change that order.
-  const unsigned wslot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u;
-  if (P.cold().stagger_prio == 1) set_prio(3u - wslot);
-  else if (P.cold().stagger_prio == 3) set_prio(wslot);
-  for (unsigned k = 0; k < wslot * (unsigned)P.cold().stagger; ++k) __builtin_amdgcn_s_sleep(1);
-  RVO3D_PRIO(0);
   Drone S;
   S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;
   double a[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
@@ -1184,7 +1155,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     }
   }
   RVO3D_STAMP(1);
-  RVO3D_PRIO(1);
   double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
   if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
   const double zero3[3] = {0, 0, 0};
@@ -1234,16 +1204,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     return;
   }
 
-  // diagnostic (RVO3D_ABLATE bit 128): zero the VO region of every row now, under the
-  // sweeps, instead of after them
-  const bool early_zero = (P.ablate & 128) && P.zf16;
-  if (early_zero) {
-    if (active) write_vo_rows(P, L, tid, lbase, g, S, 0);
-    __syncthreads();
-    zero_fill(P, L, tid, e0 * N, nrows);
-  }
   RVO3D_STAMP(2);
-  RVO3D_PRIO(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
   uint32_t gw[NW];
   const bool have_gw = P.g_cached != 0;  // the previous step ended in this very state
@@ -1264,7 +1225,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
   bool f_dest = false;
   RVO3D_STAMP(3);
-  RVO3D_PRIO(3);
   if (active) {
     max_dev = P.max_dev()[g];
     RVO3D_LOAD_CUR(P, g, cur);
@@ -1363,7 +1323,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   __syncthreads();
 
   RVO3D_STAMP(4);
-  RVO3D_PRIO(4);
   // ---- sweep B: the pair part of ir_gym.observation_reward (ir_gym.py:197).
   // In the fused auto-reset step an env that resets discards the step's VO rows (its
   // observation is recomputed after the reset), so a collision-only sweep runs first,
@@ -1384,7 +1343,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
 
   RVO3D_STAMP(5);
-  RVO3D_PRIO(5);
   if (LITE) {
     if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
     if (do_reset) L.any_reset[el] = 1;
@@ -1413,17 +1371,17 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   // everything about this drone except its VO rows is final now.  The stores wait until
   // after the last sweep (vector memory returns in order: a load behind a store waits for
-  // it), but only the rounded floats of des_vel / deviation stay live across the sweep.
-  const ProprioTail ptail = proprio_tail(dv, dev);
-  if (active) {  // file des_vel for the next step (two stores now: nothing to carry)
+  // it, and measured: stores issued here cost 1.5 %); the drone's record and the rounded
+  // floats of des_vel / deviation stay live across the sweep.
+  if (active) {
     uint32_t dvk_a, dvk_b;
-    dv_encode(dv, dvk_a, dvk_b);
+    dv_encode(dv, dvk_a, dvk_b);  // des_vel, on file for the next step
     P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
   }
+  const ProprioTail ptail = proprio_tail(dv, dev);
   if (LITE) {
     __syncthreads();
     RVO3D_STAMP(6);
-  RVO3D_PRIO(6);
     // rows for every env: ir_gym.observation_reward's VO part (the env kept its state) or
     // ir_gym.env_observation with action 0 (the env reset a drone, ir_gym.py:372-383)
     const bool env_reset = active && (L.any_reset[el] != 0);
@@ -1448,10 +1406,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);
-  RVO3D_PRIO(7);
   if (active) {
     if (!(P.ablate & 8)) {
-      write_vo_rows(P, L, tid, lbase, g, S, kept, early_zero);
+      write_vo_rows(P, L, tid, lbase, g, S, kept);
       write_proprio(P, g, S, ptail);
     }
     L.kept[tid] = kept;
@@ -1463,8 +1420,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   __syncthreads();  // L.kept complete
   RVO3D_STAMP(8);
-  RVO3D_PRIO(8);
-  if (!(P.ablate & 16) && !early_zero) zero_fill(P, L, tid, e0 * N, nrows);
+  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
   RVO3D_STAMP(9);
 }
 
