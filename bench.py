@@ -7,7 +7,7 @@ One "step" = one launch of the fused HIP step (RVO reward sweep -> integrate ->
 observation / reward / termination sweep -> auto-reset + re-observe) over the
 whole batch, with the actions already resident in HBM.
 
-    python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -78,8 +78,11 @@ def cpu_baseline(N, nm, map_size, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm", type=int, default=300,
+                    help="untimed steps before the W warmup steps (lets the GPU clocks settle; "
+                         "a launch is ~60 us, so W alone is a few ms)")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--drones", type=int, default=64)
     ap.add_argument("--nm", type=int, default=10)
@@ -119,6 +122,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for t in range(args.prewarm):
+        env.step(acts[t % n_act], autoreset=autoreset)
     for t in range(W):
         env.step(acts[t % n_act], autoreset=autoreset)
     barrier()
@@ -165,7 +170,8 @@ def main():
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "kernel": "rvo3d::env_kernel<2, NW> (fused step + auto-reset)",
+                         "traffic": traffic, "kernel": "rvo3d::env_kernel<2, 1> (fused step + auto-reset)" if N <= 64 else
+                                   "rvo3d::env_kernel<2, NW> (fused step + auto-reset)",
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_drone_step": B},
