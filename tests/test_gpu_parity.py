@@ -161,6 +161,59 @@ def run_vs_oracle(world, T, nm=10, autoreset=True, f32_actions=False, radius=Non
     return stats
 
 
+def test_values_on_file_follow_outside_state_changes():
+    """The step keeps des_vel, the stage-G words and the current / previous waypoint on file
+    between steps.  State set from outside (reset_drones, set_state with a new waypoint
+    index) must be picked up by the very next step, with no observe() in between."""
+    E, N, nm = 8, 16, 10
+    world = synthetic_world(E, N, (20.0, 20.0, 8.0), n_points=4, seed=77)
+    # short legs, so that waypoint switches happen within the run
+    wp = world.waypoints.copy()
+    for k in range(1, 4):
+        wp[:, :, k] = np.clip(np.round(wp[:, :, k - 1] + (wp[:, :, k] - wp[:, :, k - 1]) * 0.08, 2),
+                              1.0, [19.0, 19.0, 7.0])
+    world = type(world)(wp, world.n_points, world.map_size, world.buildings)
+    env = BatchedDroneEnv(world, neighbors_num=nm, action_decimals=-1)
+    ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, nm=nm,
+                        threads=8)
+    env.observe(); ref.observe()
+    tl = Tally()
+    rng = np.random.default_rng(5)
+    switches = 0
+    for t in range(40):
+        if t % 5 == 2:  # host-side reset of some drones, then step directly
+            m = rng.random((E, N)) < 0.2
+            env.reset_drones(m); ref.reset_drones(m)
+        if t % 5 == 4:  # teleport + new waypoint index, then step directly
+            st = ref.get_state()
+            pos = np.round(st["pos"] + rng.uniform(-0.5, 0.5, st["pos"].shape), 2)
+            wi = np.clip(st["wp_idx"] + rng.integers(-1, 2, st["wp_idx"].shape), 1, 3).astype(np.int32)
+            env.set_state(pos=pos, wp_idx=wi); ref.set_state(pos=pos, wp_idx=wi)
+        a = np.round(ref.get_state()["vel"] * 0.5 + synthetic_actions(E, N, t, 99), 2)
+        before = ref.get_state()["wp_idx"].copy()
+        obs, cnt, rew, done, info, fin = env.step(torch.from_numpy(a).cuda(), autoreset=(t % 2 == 0))
+        if t % 2 == 0:
+            ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(a)
+        else:
+            ro, rcnt, rr, rd, ri, rf = ref.step(a)
+        switches += int((ref.get_state()["wp_idx"] > before).sum())
+        mg = ref.margin()
+        tl.count(mg)
+        o, r = obs.cpu().numpy(), rew.cpu().numpy()
+        tl.check(f"done t={t}", done.cpu().numpy() == rd, mg)
+        tl.check(f"info t={t}", info.cpu().numpy() == ri, mg)
+        tl.check(f"finish t={t}", fin.cpu().numpy() == rf, mg)
+        tl.check(f"vo_count t={t}", cnt.cpu().numpy() == rcnt, mg)
+        tl.check(f"obs f32-exact t={t}", eq_nan(o, ro.astype(np.float32)), mg)
+        tl.check(f"reward f32-exact t={t}", eq_nan(r, rr.astype(np.float32)), mg)
+        s, rs = env.get_state(), ref.get_state()
+        assert np.array_equal(s["wp_idx"].cpu().numpy(), rs["wp_idx"]), t
+        np.testing.assert_allclose(s["max_dev"].cpu().numpy(), rs["max_dev"], rtol=1e-9, atol=1e-9)
+    assert switches > 20, switches
+    env.close()
+    print(tl.finish(), "waypoint switches", switches)
+
+
 def test_cfg2_16x256_flags_bit_exact():
     """BASELINE config 2: 16 drones x 256 envs, bit-exact collision flags vs CPU."""
     st = run_vs_oracle(synthetic_world(256, 16, (20, 20, 8)), T=60, autoreset=False)
