@@ -165,6 +165,16 @@ class BatchedDroneEnv:
                                               self._stream()), "rvo3d_get_state")
         return s
 
+    @property
+    def vel(self):
+        """drone_list[i].vel of every drone (the trainer's / evaluator's reach-through,
+        multi_ppo.py:202, post_train.py:72): a fresh [E, N, 3] float64 copy."""
+        v = torch.empty((self.E, self.N, 3), dtype=torch.float64, device=self.device)
+        none = [None] * 8
+        _lib.check(_lib.lib().rvo3d_get_state(self._h, None, _ptr(v), *none, self._stream()),
+                   "rvo3d_get_state")
+        return v
+
     def set_state(self, **kw):
         order = ("pos", "vel", "yaw", "pitch", "real_len", "max_dev", "extra_len", "wp_idx",
                  "arrive", "dest")

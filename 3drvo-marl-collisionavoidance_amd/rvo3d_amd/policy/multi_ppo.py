@@ -152,7 +152,9 @@ class multi_ppo:
             # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
             # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
             obs, cnt, rew, done, info, fin = env.step_policy(a, autoreset=True)
-            a_inc = torch.round(a * 100.0) / 100.0  # what the reference stores (multi_ppo.py:197)
+            # what the reference stores (multi_ppo.py:197): rint(a * 100) / 100 in float32 with a
+            # true division (a scalar divisor would become a multiplication by 1/100)
+            a_inc = torch.round(a * 100.0) / torch.full_like(a, 100.0)
             if self.sanitize_rewards:
                 rew = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
             buf.store(prev_obs, prev_cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))

@@ -376,3 +376,52 @@ def test_training_loop_end_to_end(kind, tmp_path):
     assert set(ck) == {"model_state", "pi_optimizer", "vf_optimizer"}   # multi_ppo.py:411-412
     assert env.error_flags() == 0
     env.close()
+
+
+def test_post_train_policy_test_matches_a_sequential_restatement():
+    """post_train.policy_test (post_train.py:38-128) batched over E envs == the reference's
+    loop restated in numpy on the oracle, episode by episode (same scripted policy output)."""
+    from rvo3d_amd.policy import post_train
+    E, N, nm, T = 6, 8, 10, 400
+    world = synthetic_world(E, N, (12.0, 12.0, 6.0), seed=5)
+    acts = [torch.from_numpy(synthetic_actions(E, N, t, 321).astype(np.float32)).cuda() for t in range(T)]
+
+    class Scripted:
+        def __init__(self): self.t = 0
+        def eval(self): return self
+        def step_tensors(self, obs, std_factor=1):
+            a = acts[self.t].view(-1, 3); self.t += 1
+            return a, None, None
+
+    env = BatchedDroneEnv(world, neighbors_num=nm, action_decimals=-1)
+    pt = post_train(env, num_episodes=14, max_ep_len=25, acceler_vel=1.0, inf_print=False)
+    got = pt.policy_test(policy=Scripted())
+    env.close()
+
+    ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, nm=nm, threads=8)
+    ref.reset(); ref.observe()
+    ep_len = np.zeros(E, np.int64); speed_sum = np.zeros(E); n = sn = 0
+    lens, speeds = [], []
+    t = 0
+    while n < 14:
+        a_inc = np.round(acts[t].cpu().numpy(), 2); t += 1             # float32
+        action = (np.float32(1.0) * a_inc).astype(np.float64) + ref.get_state()["vel"]
+        ro, rcnt, rr, rd, ri, rf = ref.step(action)
+        speed_sum += np.linalg.norm(ref.get_state()["vel"], axis=-1).mean(axis=1)
+        ep_len += 1
+        ended = rd.astype(bool).any(axis=1) | (ep_len == 25) | rf.astype(bool).all(axis=1)
+        for e in np.nonzero(ended)[0]:
+            if n >= 14:
+                break
+            if ri[e].astype(bool).all():
+                lens.append(int(ep_len[e]))
+            speeds.append(speed_sum[e] / ep_len[e]); n += 1
+            sn += int(rf[e].astype(bool).all())
+        if ended.any():
+            ref.reset(ended.astype(np.uint8)); ref.observe()
+            ep_len[ended] = 0; speed_sum[ended] = 0
+    assert got["episodes"] == 14
+    assert got["success_rate"] == sn / 14
+    assert got["ep_len"] == lens
+    np.testing.assert_allclose(got["speed"], speeds, rtol=1e-12)
+    assert got["average_speed"] == float(np.round(np.mean(speeds), 2))
