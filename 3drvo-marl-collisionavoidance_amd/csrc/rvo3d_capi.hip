@@ -416,6 +416,22 @@ int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
   return RVO3D_OK;
 }
 
+int rvo3d_rvo_vel(rvo3d_env* h, const double* vmax, double acceler, double* out_vel, void* stream) {
+  int rc = check(h, true);
+  if (rc) return rc;
+  if (!vmax || !out_vel) return fail(RVO3D_ERR_INVALID, "vmax / out_vel are required");
+  if (!(acceler >= 0.0 && acceler <= 1.0))
+    return fail(RVO3D_ERR_INVALID, "acceler must be in [0, 1] (at most 4 candidates per axis)");
+  rvo3d::RvoVelArgs A;
+  for (int k = 0; k < 3; ++k) A.vmax[k] = vmax[k];
+  A.acceler = acceler;
+  const int T = (int)align_up((size_t)h->P.N, 64);
+  hipLaunchKernelGGL(rvo3d::rvo_vel_kernel, dim3((unsigned)h->P.E), dim3((unsigned)T),
+                     (size_t)T * 8 * sizeof(double), static_cast<hipStream_t>(stream), h->P, A, out_vel);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+
 int rvo3d_state_ptrs(rvo3d_env* h, rvo3d_state_view* out) {
   if (!h || !out) return fail(RVO3D_ERR_INVALID, "null argument");
   const Params& P = h->P;

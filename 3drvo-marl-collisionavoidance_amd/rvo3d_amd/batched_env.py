@@ -151,6 +151,15 @@ class BatchedDroneEnv:
         _lib.check(_lib.lib().rvo3d_des_vel(self._h, _ptr(out), self._stream()), "rvo3d_des_vel")
         return out
 
+    def rvo_vel(self, vmax=(2.0, 2.0, 2.0), acceler: float = 0.5):
+        """reciprocal_vel_obs.cal_vel for every drone (reciprocal_vel_obs.py:19-31, as
+        intended: see include/rvo3d.h): the classical RVO velocity, [E, N, 3] float64."""
+        out = torch.empty((self.E, self.N, 3), dtype=torch.float64, device=self.device)
+        vm = (C.c_double * 3)(*[float(x) for x in vmax])
+        _lib.check(_lib.lib().rvo3d_rvo_vel(self._h, vm, float(acceler), _ptr(out), self._stream()),
+                   "rvo3d_rvo_vel")
+        return out
+
     # -- state ------------------------------------------------------------------------
     def get_state(self):
         E, N, dev = self.E, self.N, self.device

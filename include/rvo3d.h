@@ -138,6 +138,17 @@ int rvo3d_step_policy(rvo3d_env *h, const float *a_inc, float acceler, float *ob
 /* ir_gym.cal_des_list (ir_gym.py:44): desired velocity, des_vel [E][N][3] f64. */
 int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
 
+/* reciprocal_vel_obs.cal_vel (uaisa_env/vel_obs/reciprocal_vel_obs.py:19-31) for every drone
+ * on the current state: candidate velocities on a 0.5 grid inside clip([v - acceler,
+ * v + acceler], -vmax, vmax), |v| >= 0.3, tested against the reciprocal velocity obstacle
+ * of every drone within 10 m; the one closest to the desired velocity outside all cones,
+ * else the inside one with the least penalty, else 0.  The reference class cannot run as
+ * written; this is the algorithm it spells out, on the helper functions it calls
+ * (parity unpinned for the driver loop).  vmax: HOST [3]; 0 <= acceler
+ * <= 1; out_vel [E][N][3] f64. */
+int rvo3d_rvo_vel(rvo3d_env *h, const double *vmax, double acceler, double *out_vel,
+                  void *stream);
+
 /* Zero-copy views of the state arrays. */
 int rvo3d_state_ptrs(rvo3d_env *h, rvo3d_state_view *out);
 /* Array-of-structs copies: pos/vel [E][N][3] f64, the rest [E][N]; any

@@ -49,6 +49,7 @@ def lib():
         L.orc_get_state.argtypes = [vp] + [dp] * 7 + [ip, bp, bp]
         L.orc_set_state.argtypes = [vp] + [dp] * 7 + [ip, bp, bp]
         L.orc_des_vel.argtypes = [vp, dp]
+        L.orc_rvo_vel.argtypes = [vp, dp, C.c_double, dp]
         L.orc_vo_inf.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, ip, dp, ip]
         L.orc_get_margin.argtypes = [vp, dp, ip]
         L.orc_nan_count.restype = C.c_int64
@@ -176,6 +177,13 @@ class OracleEnv:
     def des_vel(self):
         out = np.empty((self.E, self.N, 3))
         lib().orc_des_vel(self._h, _dp(out))
+        return out
+
+    def rvo_vel(self, vmax=(2.0, 2.0, 2.0), acceler=0.5):
+        """Classical RVO velocity selection (reciprocal_vel_obs.py as intended): [E, N, 3]."""
+        out = np.empty((self.E, self.N, 3))
+        vm = np.ascontiguousarray(vmax, dtype=np.float64)
+        lib().orc_rvo_vel(self._h, _dp(vm), float(acceler), _dp(out))
         return out
 
     def vo_inf(self, e, i, action):

@@ -801,6 +801,127 @@ void orc_des_vel(const orc_env *h, double *des_vel) {
     cal_des_vel(h->p + 3 * (size_t)g, wp_at(h, g, h->wp_idx[g]), des_vel + 3 * (size_t)g);
 }
 
+/* ---- classical RVO velocity selection ---------------------------------------
+ * uaisa_env/vel_obs/reciprocal_vel_obs.py:19-166 (cal_vel -> preprocess, config_vo,
+ * vel_candidate, vo_out2, vel_select, penalty).  The reference class cannot run (list
+ * attribute assignment at :109, slices [0:4] / [4:6] at :63-69 / :105, a missing
+ * return at :119-124, cal_vel's config_vo call at :24); this is the algorithm the code
+ * spells out, built from the helpers it calls (vel_obs3D.get_alpha / get_PAA /
+ * get_rvo_array / get_beta / cal_exp_tim, which do run).  PARITY UNPINNED for the
+ * driver loop; the helpers are pinned by tests/golden/rvo_vel.npz (gen_golden_rvo.py).
+ * Choices where the reference raises: asin domain (overlap) -> alpha = 1.57; no
+ * candidate at all -> velocity 0. */
+static double cal_exp_tim_classic(const double *pa, const double *pb, const double *va,
+                                  const double *vb, double ra, double rb) {
+  /* vel_obs3D.cal_exp_tim (vel_obs3D.py:104-143) */
+  double rx = pa[0] - pb[0], ry = pa[1] - pb[1], rz = pa[2] - pb[2];
+  double vx = va[0] - vb[0], vy = va[1] - vb[1], vz = va[2] - vb[2];
+  double r = ra + rb;
+  double a = sq(vx) + sq(vy) + sq(vz);
+  double b = 2 * rx * vx + 2 * ry * vy + 2 * rz * vz;
+  double c = sq(rx) + sq(ry) + sq(rz) - sq(r);
+  if (c <= 0) return 0.0;
+  double temp = sq(b) - 4 * a * c;
+  if (temp <= 0) return INFINITY;
+  double t1 = (-b + sqrt(temp)) / (2 * a);
+  double t2 = (-b - sqrt(temp)) / (2 * a);
+  double t3 = t1 >= 0 ? t1 : INFINITY, t4 = t2 >= 0 ? t2 : INFINITY;
+  return t3 < t4 ? t3 : t4;  /* min(t3, t4) */
+}
+
+static double get_beta_classic(const double *A, const double *B) { /* vel_obs3D.py:44-66 */
+  double dotp = dot3_blas(A, B);
+  double AB = norm3_blas(A) * norm3_blas(B);
+  double c = (AB != 0) ? dotp / AB : 0.0;
+  double ang = acos(c);
+  if (ang > M_PI) ang -= 2 * M_PI;  /* wraptopi */
+  if (ang < -M_PI) ang += 2 * M_PI;
+  return np_round2(ang);            /* round(np.float64, 2) */
+}
+
+/* np.arange(lo, hi, 0.5): value k (numpy fills start + k * ((start + step) - start)) */
+static int arange_len(double lo, double hi) {
+  double n = ceil((hi - lo) / 0.5);
+  return n > 0 ? (int)n : 0;
+}
+static double arange_at(double lo, int k) {
+  if (k == 0) return lo;
+  double next = lo + 0.5;
+  if (k == 1) return next;
+  return lo + k * (next - lo);
+}
+
+#define ORC_RVO_MAXC 512
+void orc_rvo_vel(const orc_env *h, const double *vmax, double acceler, double *out) {
+  const int N = h->N;
+#pragma omp parallel for schedule(static) num_threads(h->threads)
+  for (int g = 0; g < h->E * N; ++g) {
+    const int e = g / N;
+    const double *pa = h->p + 3 * (size_t)g, *va = h->v + 3 * (size_t)g;
+    const double ra = h->radius[g], pra = h->prio[g];
+    double des[3];
+    cal_des_vel(pa, wp_at(h, g, h->wp_idx[g]), des);
+    double lo[3], hi[3];
+    int cnt[3];
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = clampd(va[k] - acceler, -vmax[k], vmax[k]);  /* np.clip */
+      hi[k] = clampd(va[k] + acceler, -vmax[k], vmax[k]);
+      cnt[k] = arange_len(lo[k], hi[k]);
+    }
+    double best_out = INFINITY, best_in = INFINITY;
+    double sel_out[3] = {0, 0, 0}, sel_in[3] = {0, 0, 0};
+    int have_out = 0, have_in = 0;
+    /* tc_min over the neighbours in range (penalty, :126-147) */
+    double tc_min = INFINITY;
+    for (int j = 0; j < N; ++j) {
+      const int gj = e * N + j;
+      if (gj == g) continue;
+      const double *pb = h->p + 3 * (size_t)gj;
+      double dif[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+      if (!(norm3_blas(dif) <= 10)) continue;
+      double tc = cal_exp_tim_classic(pa, pb, va, h->v + 3 * (size_t)gj, ra, h->radius[gj]);
+      if (tc < tc_min) tc_min = tc;
+    }
+    const double tc_inv = (tc_min == 0) ? INFINITY : 1.0 / tc_min;
+    for (int ix = 0; ix < cnt[0] && ix < ORC_RVO_MAXC; ++ix)
+      for (int iy = 0; iy < cnt[1] && iy < ORC_RVO_MAXC; ++iy)
+        for (int iz = 0; iz < cnt[2] && iz < ORC_RVO_MAXC; ++iz) {
+          const double v[3] = {arange_at(lo[0], ix), arange_at(lo[1], iy), arange_at(lo[2], iz)};
+          if (sqrt(sq(v[0]) + sq(v[1]) + sq(v[2])) < 0.3) continue;
+          const double pn[3] = {pa[0] + v[0] * 1, pa[1] + v[1] * 1, pa[2] + v[2] * 1};
+          int inside = 0;
+          for (int j = 0; j < N; ++j) {  /* vo_out2 over the VO list */
+            const int gj = e * N + j;
+            if (gj == g) continue;
+            const double *pb = h->p + 3 * (size_t)gj, *vb = h->v + 3 * (size_t)gj;
+            double dif[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
+            if (!(norm3_blas(dif) <= 10)) continue;
+            double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+            double q = (ra + h->radius[gj]) / norm3_blas(ab);
+            double alpha = (q <= 1.0) ? orc_py_round2(asin(q)) : 1.57;  /* get_alpha */
+            double pr = pra / (pra + h->prio[gj]);                      /* get_PAA */
+            double paa[3] = {pr * (2 * pa[0] + (va[0] + vb[0]) * 1),
+                             pr * (2 * pa[1] + (va[1] + vb[1]) * 1),
+                             pr * (2 * pa[2] + (va[2] + vb[2]) * 1)};
+            double w[3] = {pn[0] - paa[0], pn[1] - paa[1], pn[2] - paa[2]};
+            double beta = get_beta_classic(ab, w);
+            if (alpha > beta) inside = 1;
+          }
+          const double dd = sqrt(sq(des[0] - v[0]) + sq(des[1] - v[1]) + sq(des[2] - v[2]));
+          if (!inside) {  /* min(vo_outside, key=distance): the first minimum */
+            if (!have_out || dd < best_out) { best_out = dd; memcpy(sel_out, v, sizeof v); have_out = 1; }
+          } else {        /* min(vo_inside, key=penalty) */
+            const double pen = 1 * tc_inv + dd;
+            if (!have_in || pen < best_in) { best_in = pen; memcpy(sel_in, v, sizeof v); have_in = 1; }
+          }
+        }
+    double *o = out + 3 * (size_t)g;
+    if (have_out) memcpy(o, sel_out, sizeof sel_out);
+    else if (have_in) memcpy(o, sel_in, sizeof sel_in);
+    else o[0] = o[1] = o[2] = 0.0;
+  }
+}
+
 void orc_vo_inf(orc_env *h, int e, int i, const double *action, double *rows,
                 int32_t *count, int32_t *vo_flag, double *tmin, int32_t *collision) {
   work *w = work_alloc(h);

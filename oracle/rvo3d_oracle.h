@@ -75,6 +75,10 @@ void orc_set_state(orc_env *h, const double *pos, const double *vel,
 
 /* ir_gym.cal_des_list (ir_gym.py:44): desired velocity [E][N][3]. */
 void orc_des_vel(const orc_env *h, double *des_vel);
+/* Classical RVO velocity selection of every drone on the current state
+ * (reciprocal_vel_obs.py:19-166 as intended; the class itself cannot run: PARITY UNPINNED
+ * for the driver loop, see the .c).  vmax[3], acceler; out [E*N][3]. */
+void orc_rvo_vel(const orc_env *h, const double *vmax, double acceler, double *out);
 
 /* Call-level check of rvo_inter.config_vo_inf (rvo_inter.py:20-61) for drone i
  * of env e against the current state, with an arbitrary action.  rows
