@@ -74,6 +74,7 @@ int carve(rvo3d_env* h) {
       {(void**)&P.u8, 2 * S},
       {(void**)&C.bld, (size_t)(c.num_buildings > 0 ? c.num_buildings : 1) * 4 * 8},
       {(void**)&C.pow95, (size_t)c.max_points * 8},
+      {(void**)&C.bgrid, (size_t)(C.bgx > 0 ? C.bgx * C.bgy : 1) * (rvo3d::kBgridK + 1) * 2},
       {(void**)&P.err, 256},
       {(void**)&P.cold_, sizeof(rvo3d::Cold)},
   };
@@ -163,6 +164,16 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   for (int k = 0; k < 3; ++k) C.map[k] = cfg->map_size[k];
   P.T10 = sq_threshold(10.0);  // rvo_inter.py:96
   C.T5 = sq_threshold(5.0);    // rvo_inter.py:104
+  C.bgx = C.bgy = 0; C.bg_inv = 0.0;
+  if (cfg->num_buildings > 0 && cfg->map_size[0] > 0 && cfg->map_size[1] > 0 &&
+      std::isfinite(cfg->map_size[0]) && std::isfinite(cfg->map_size[1])) {
+    // xy grid for the building gate: ~8 m cells, at most 64 x 64
+    const double cs = std::fmax(8.0, std::fmax(cfg->map_size[0], cfg->map_size[1]) / 64.0);
+    C.bgx = (int)std::ceil(cfg->map_size[0] / cs); C.bgy = (int)std::ceil(cfg->map_size[1] / cs);
+    if (C.bgx < 1) C.bgx = 1;
+    if (C.bgy < 1) C.bgy = 1;
+    C.bg_inv = 1.0 / cs;
+  }
   C.T04 = sq_threshold(0.4);   // drone.py:15 goal_threshold
   {
     // fp32 candidate filter (stage G).  Coordinates are centred on the map and
@@ -299,8 +310,37 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   HIP_TRY(hipMemcpyAsync((void*)P.radius(), rad.data(), EN * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync((void*)P.prio(), pri.data(), EN * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync((void*)C.pow95, p95.data(), (size_t)P.P * 8, hipMemcpyHostToDevice, s));
-  if (C.nb > 0)
+  std::vector<uint16_t> grid;
+  if (C.nb > 0) {
     HIP_TRY(hipMemcpyAsync((void*)C.bld, buildings, (size_t)C.nb * 32, hipMemcpyHostToDevice, s));
+    if (C.bgx > 0) {
+      // cell (ix, iy) = [ix*cs, (ix+1)*cs] x [iy*cs, (iy+1)*cs], widened by 1e-3 m (the device
+      // finds the cell with floor(x / cs) in floating point) and unbounded at the map's edge
+      // (clamped lookups); a building is listed where its 5 m gate circle reaches the cell
+      const int K = rvo3d::kBgridK;
+      const double cs = 1.0 / C.bg_inv, reach = 5.0 + 1e-3;
+      grid.assign((size_t)C.bgx * C.bgy * (K + 1), 0);
+      for (int ix = 0; ix < C.bgx; ++ix)
+        for (int iy = 0; iy < C.bgy; ++iy) {
+          uint16_t* cell = &grid[((size_t)ix * C.bgy + iy) * (K + 1)];
+          const double x0 = ix == 0 ? -INFINITY : ix * cs, x1 = ix == C.bgx - 1 ? INFINITY : (ix + 1) * cs;
+          const double y0 = iy == 0 ? -INFINITY : iy * cs, y1 = iy == C.bgy - 1 ? INFINITY : (iy + 1) * cs;
+          int n = 0;
+          bool overflow = false;
+          for (int b = 0; b < C.nb && !overflow; ++b) {
+            const double bx = buildings[4 * b], by = buildings[4 * b + 1];
+            const double dx = bx < x0 ? x0 - bx : (bx > x1 ? bx - x1 : 0.0);
+            const double dy = by < y0 ? y0 - by : (by > y1 ? by - y1 : 0.0);
+            if (!(dx * dx + dy * dy > reach * reach)) {  // also keeps NaN centres
+              if (n == K || b > 0xfffe) overflow = true;
+              else cell[1 + n++] = (uint16_t)b;
+            }
+          }
+          cell[0] = overflow ? 0xffff : (uint16_t)n;
+        }
+      HIP_TRY(hipMemcpyAsync((void*)C.bgrid, grid.data(), grid.size() * 2, hipMemcpyHostToDevice, s));
+    }
+  }
   HIP_TRY(hipMemsetAsync(P.extra_len(), 0, EN * 8, s));
   const int tb = 256;
   hipLaunchKernelGGL(rvo3d::dv0_kernel, dim3((unsigned)((EN + tb - 1) / tb)), dim3(tb), 0, s, P);

@@ -59,7 +59,14 @@ struct Cold {
   int nb;
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
+  // building grid over the map's xy plane (rvo3d_load_world): cell (ix, iy) lists every
+  // building whose 5 m gate circle reaches the cell, kBgridK + 1 u16 per cell = count, indices;
+  // count 0xffff = more than kBgridK: test all.  bgx == 0: no grid.
+  const uint16_t* bgrid;
+  int bgx, bgy;
+  double bg_inv;           // 1 / cell size
 };
+constexpr int kBgridK = 15;
 typedef const __attribute__((address_space(4))) Cold ColdC;
 
 struct Params {
@@ -845,20 +852,39 @@ __device__ __forceinline__ uint32_t regate_resets(const Params& P, const Lds& L,
 }
 
 // building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
+__device__ __forceinline__ bool building_test(const double* const bld, int b, const Drone& S,
+                                              double T5) {
+  const double bx = bld[4 * b], by = bld[4 * b + 1], bh = bld[4 * b + 2], br = bld[4 * b + 3];
+  const double ex = S.x - bx, ey = S.y - by;
+  // h > z - 2 and norm <= 5 (gate), z <= h, then dis <= r + br on the few that pass
+  if ((bh > S.z - 2) & (norm2sq(ex, ey) <= T5) & (S.z <= bh))
+    return __builtin_sqrt(sq(ex) + sq(ey)) <= S.r + br;
+  return false;
+}
 __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
+  const int nb = P.cold().nb;
+  if (nb == 0) return false;
   bool hit = false;
-  for (int b = 0; b < P.cold().nb; ++b) {
-    const double bx = P.cold().bld[4 * b], by = P.cold().bld[4 * b + 1], bh = P.cold().bld[4 * b + 2],
-                 br = P.cold().bld[4 * b + 3];
-    if (bh > S.z - 2) {
-      if (norm2sq(S.x - bx, S.y - by) <= P.cold().T5) {  // norm <= 5
-        if (S.z <= bh) {
-          double dis = __builtin_sqrt(sq(S.x - bx) + sq(S.y - by));
-          if (dis <= S.r + br) hit = true;
-        }
-      }
+  const double* const bld = P.cold().bld;
+  const double T5 = P.cold().T5;
+  const int gx = P.cold().bgx;
+  if (gx > 0) {
+    // only the buildings listed for the drone's cell can pass the 5 m gate (the lists are
+    // conservative; a drone outside the map collides anyway and NaN passes no test)
+    const int gy = P.cold().bgy;
+    const double inv = P.cold().bg_inv;
+    int ix = (int)__builtin_floor(S.x * inv), iy = (int)__builtin_floor(S.y * inv);
+    ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
+    const uint16_t* const cell = P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1);
+    const int cnt = cell[0];
+    if (cnt != 0xffff) {
+      for (int k = 0; k < cnt; ++k) hit |= building_test(bld, cell[1 + k], S, T5);
+      return hit;
     }
   }
+#pragma unroll 4
+  for (int b = 0; b < nb; ++b) hit |= building_test(bld, b, S, T5);
   return hit;
 }
 
