@@ -1,0 +1,474 @@
+// rvo3d_pairs.hpp -- The pair pipeline: exact pair evaluation (stage X2) and kept-row insertion, the fp32 stages G
+// and X1, the symmetric sweep, the collision-only sweep and the incremental re-gating after resets.
+// Part of the gfx950 device code (see rvo3d_device.hpp for the overview).
+#pragma once
+
+#include "rvo3d_lds.hpp"
+
+namespace rvo3d {
+
+// min_dis of a kept row, recomputed from LDS exactly as pair_eval computed it.
+__device__ __forceinline__ double pair_md(const Drone& S, const Drone& O) {
+  double rx = O.x - S.x, ry = O.y - S.y, rz = O.z - S.z;
+  return __builtin_sqrt(sq(ry) + sq(rx) + sq(rz)) - O.r;
+}
+
+// Stage X: the exact fp64 evaluation of one candidate pair = the neighbour gate of
+// rvo_inter.preprocess (rvo_inter.py:90-97) followed by rvo_inter.config_vo_circle2
+// (rvo_inter.py:116-196) with get_alpha / get_PAA / vo_out_jud_vector / get_beta
+// (vel_obs3D.py:8-66, rvo_inter.py:212-228).  `a` is the action after the
+// "< 1e-5 -> 0" rule (rvo_inter.py:118).
+__device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, const Lds& L, int k,
+                                             const double a[3]) {
+  PairOut o;
+  o.flag = false; o.collision = false; o.t = 0.0; o.iet = 0.0; o.md = 0.0; o.alpha_c = 0;
+  const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
+  const double d2 = dot3b(rx, ry, rz, rx, ry, rz);  // np.linalg.norm(dif) ** 2 (sign-symmetric)
+  // gate: norm <= 10 (rvo_inter.py:96) and not the very same position (rvo_inter.py:92)
+  if (!(d2 <= P.T10)) return o;
+  if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) return o;
+  const double Or = L.r[k];
+  const double ssum = sq(ry) + sq(rx) + sq(rz);  // dis ** 2 as rvo_inter.py:135 sums it
+  const double R = S.r + Or;
+  // dis <= thr without the sqrt unless ssum is within 1e-15 (relative) of thr^2
+  const double thr = P.env_train ? R : (S.r - kExpRadius + Or);
+  const double thr2 = thr * thr;
+  bool coll;
+  if (ssum < thr2 * (1.0 - 1e-15)) coll = thr >= 0;
+  else if (ssum > thr2 * (1.0 + 1e-15)) coll = false;
+  else coll = __builtin_sqrt(ssum) <= thr;
+  if (coll) { o.collision = true; return o; }
+  const double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
+  if (dotp <= 0) return o;
+  const double Ovx = L.vx[k], Ovy = L.vy[k], Ovz = L.vz[k], Oprio = L.prio[k];
+  // get_PAA (vel_obs3D.py:19-32); x / (x + x) == 0.5 exactly
+  const double pr = (S.prio == Oprio) ? 0.5 : S.prio / (S.prio + Oprio);
+  const double paax = pr * (2 * S.x + (S.vx + Ovx));
+  const double paay = pr * (2 * S.y + (S.vy + Ovy));
+  const double paaz = pr * (2 * S.z + (S.vz + Ovz));
+  const double wx = (S.x + 2 * a[0]) - paax, wy = (S.y + 2 * a[1]) - paay,
+               wz = (S.z + 2 * a[2]) - paaz;
+  const double dp = dot3b(rx, ry, rz, wx, wy, wz);
+  // dp <= 0: cos <= 0 (or AB == 0 -> cos := 0), beta >= pi/2, beta_c >= 157 >= alpha_c: outside
+  if (dp <= 0) return o;
+  const double w2 = dot3b(wx, wy, wz, wx, wy, wz);
+  // Conservative pre-filter.  Inside needs alpha_c >= beta_c + 1, which implies
+  // beta_raw <= alpha_raw; so cos(beta) < cos(alpha + 1e-4) is surely outside.
+  // |ab| cos(alpha + d) = cos d sqrt(d2 - R^2) - sin d R =: K, cos(beta) = dp / (|ab| |w|).
+  // The square root is taken in fp32 (1e-7 relative); the 1e-5 slack on K^2 covers it.
+  const double K = kCosD * (double)__builtin_sqrtf((float)(d2 - R * R)) - kSinD * R;
+  if (K > 0 && dp * dp < (w2 * (K * K)) * (1.0 - 1e-5)) return o;
+  const double nab = __builtin_sqrt(d2);
+  const double alpha_c = py_round2_c(asin(R / nab));
+  const double AB = nab * __builtin_sqrt(w2);
+  const double cosang = (AB != 0) ? dp / AB : 0.0;
+  const double beta_c = __builtin_rint(acos(cosang) * 100.0);  // NaN when |cos| > 1 (np.arccos)
+  if (!(alpha_c > beta_c)) return o;  // alpha > beta on the rounded values (rvo_inter.py:226)
+  const double rvx = 2 * a[0] - Ovx - S.vx, rvy = 2 * a[1] - Ovy - S.vy,
+               rvz = 2 * a[2] - Ovz - S.vz;
+  const double t = vo_exp_time(rx, ry, rz, rvx, rvy, rvz, S.r, Or);
+  if (t < kCtimeThreshold) {
+    o.flag = true;
+    o.t = t;
+    o.iet = 1 / (t + 0.2);
+    o.md = __builtin_sqrt(ssum) - Or;
+    o.alpha_c = (int)alpha_c;
+  }
+  return o;
+}
+
+// Insert one flagged pair into the kept VO rows of lane `tid` (LDS), keeping the nm
+// most urgent in the order of list.sort(reverse=True, key=(-iet, min_dis)) (stable):
+// ascending iet, then descending min_dis, then ascending j; slot 0 = least urgent
+// kept.  The order is total, so the result does not depend on insertion order.
+__device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, int lbase,
+                                          const Drone& S, const PairOut& po, int j, int kept) {
+  const size_t T = P.S;  // slot stride of the row scratch
+  double* const iet = P.row_iet(0) + g;
+  uint32_t* const pk = P.row_pk(0) + g;
+  // position among kept rows: first slot whose row is more urgent than the new one
+  int pos = kept;
+  for (int s = 0; s < kept; ++s) {
+    const double ie = iet[s * T];
+    bool new_first;  // new row sorts before slot s
+    if (po.iet != ie) new_first = po.iet < ie;
+    else {
+      const int js = (int)(pk[s * T] & 0xffffu);
+      const double mds = pair_md(S, lds_drone(L, lbase + js));
+      new_first = (po.md != mds) ? (po.md > mds) : (j < js);
+    }
+    if (new_first) { pos = s; break; }
+  }
+  const uint32_t packed = ((uint32_t)po.alpha_c << 16) | (uint32_t)j;
+  if (kept < P.nm) {  // grow: shift [pos, kept) up by one
+    for (int s = kept; s > pos; --s) {
+      iet[s * T] = iet[(s - 1) * T];
+      pk[s * T] = pk[(s - 1) * T];
+    }
+    iet[pos * T] = po.iet;
+    pk[pos * T] = packed;
+    ++kept;
+  } else if (pos > 0) {  // full: drop slot 0 (least urgent), insert at pos-1
+    for (int s = 0; s < pos - 1; ++s) {
+      iet[s * T] = iet[(s + 1) * T];
+      pk[s * T] = pk[(s + 1) * T];
+    }
+    iet[(pos - 1) * T] = po.iet;
+    pk[(pos - 1) * T] = packed;
+  }
+  return kept;
+}
+
+// ===== the pair pipeline: whole envs per workgroup, fp32 filters, exact stage on request =====
+enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
+
+// fp32 image of one drone, written to both copies of its env segment.
+__device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el, int d,
+                                          bool active, const double p[3], const double v[3],
+                                          const double az[3], double r, double prio) {
+  if (!active) return;
+  const double cx = p[0] - P.cold().cen[0], cy = p[1] - P.cold().cen[1], cz = p[2] - P.cold().cen[2];
+  const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
+  const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
+                         P.cold().kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
+                         (float)az[0], (float)az[1], (float)az[2], (float)prio};
+  const int o = el * 2 * P.N + d, os = el * P.N + d;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    if (k == WX || k == WY || k == WZ || k == WR) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
+    else L.w[k][os] = val[k];
+  }
+  const double cm = (double)P.cold().cmax;
+  if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))
+    L.far[el] = 1;
+}
+
+// Offsets 1..N/2 a drone is responsible for, as NW words of 32 bits (bit b of word w =
+// offset 32w + b + 1).  With N even the offset N/2 belongs to the drones d < N/2 only.
+template <int NW>
+__device__ __forceinline__ void valid_offsets(int N, int d, uint32_t valid[NW]) {
+  const int H = N >> 1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const int n = H - 32 * w;
+    valid[w] = n >= 32 ? 0xffffffffu : (n > 0 ? ((1u << n) - 1u) : 0u);
+  }
+  if (!(N & 1) && d >= H && H > 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (((H - 1) >> 5) == w) valid[w] &= ~(1u << ((H - 1) & 31));
+  }
+}
+
+// Stage G for the offsets of word w (packed fp32, two offsets per instruction): squared
+// distance to neighbour d + k against the threshold(s).  TOUCHONLY: possibly touching
+// (and in range); else: possibly in range.
+template <bool TOUCHONLY>
+__device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int o0, int w, int H,
+                                              float mex, float mey, float mez, float mer,
+                                              uint32_t* range_out = nullptr) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
+  const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
+  uint32_t m = 0u, mr = 0u;
+#pragma unroll 8
+  for (int b = 0; b < kend; b += 2) {
+    const int o = o0 + 32 * w + b + 1;
+    const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
+    const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
+    const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
+    v2f d2 = dx * dx;
+    d2 = __builtin_elementwise_fma(dy, dy, d2);
+    d2 = __builtin_elementwise_fma(dz, dz, d2);
+    uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
+    if (TOUCHONLY) {
+      if (range_out) mr |= (b0 | (b1 << 1)) << b;  // the in-range word on the side
+      const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
+      const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
+                                               (v2f){P.band, P.band});
+      b0 &= (uint32_t)(d2.x <= rc.x);
+      b1 &= (uint32_t)(d2.y <= rc.y);
+    }
+    m |= (b0 | (b1 << 1)) << b;
+  }
+  if (TOUCHONLY && range_out) *range_out = mr;
+  return m;
+}
+
+// Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
+// drone whose index d satisfies j = d + k (mod N), 1 <= k <= N/2.
+//   stage G  (packed fp32, all offsets): possibly in range;
+//   stage X1 (fp32, candidates): possibly approaching / touching and a conservative
+//            cone pre-filter, for both directions; survivors request the exact
+//            evaluation from the owner (bit masks, LDS atomics);
+//   stage X2 (fp64, requested pairs only): pair_eval.
+// G and X1 only ever drop pairs that pair_eval would return "nothing" for.
+// NW = ceil(N / 64): words per request mask (64 drones) and per offset mask (32 offsets).
+template <int NW, bool ROWS, bool TOUCH>
+__device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
+                                         int g, bool active, const Drone& S, const double a[3],
+                                         bool zero_act, bool& flag, double& tmin,
+                                         bool& collision, uint32_t gw[NW], bool have_gw) {
+  flag = false;
+  tmin = __builtin_inf();
+  int kept = 0;
+  const int N = P.N, H = N >> 1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) L.mask2[lane * NW + w] = 0ull;
+  __syncthreads();
+  unsigned long long m2r = 0ull;  // NW == 1: my own requests stay in a register
+  if (active) {
+    const int o0 = el * 2 * N + d, os0 = el * N + d;
+    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
+    const float mvx = L.w[WVX][os0], mvy = L.w[WVY][os0], mvz = L.w[WVZ][os0];
+    const float mer = L.w[WR][o0], mkd = L.w[WKD][os0], mprio = L.w[WPRIO][os0];
+    const float max_ = zero_act ? 0.f : L.w[WAX][os0], may = zero_act ? 0.f : L.w[WAY][os0],
+                maz = zero_act ? 0.f : L.w[WAZ][os0];
+    const bool far = L.far[el] != 0;
+    uint32_t valid[NW];
+    valid_offsets<NW>(N, d, valid);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      if (ROWS && !TOUCH) RVO3D_STAMP(10);
+      // stage G, unless the words of this very state are on file (gw in, have_gw)
+      uint32_t cand;
+      if (have_gw) cand = gw[w];
+      else {
+        cand = far ? valid[w] : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+        gw[w] = cand;
+      }
+      if (P.ablate & 64) cand = 0;
+      if (ROWS && !TOUCH) RVO3D_STAMP(11);
+      // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd
+      // count repeats its last candidate: the requests are idempotent ORs)
+      typedef float v2f __attribute__((ext_vector_type(2)));
+      const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
+      const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};
+      const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
+                taz = {2.f * maz, 2.f * maz};
+      const int fr = far ? 1 : 0;
+      while (cand) {
+        const int kb0 = __builtin_ctz(cand);
+        cand &= cand - 1;
+        const bool two = cand != 0u;
+        const int kb1 = two ? __builtin_ctz(cand) : kb0;
+        cand &= cand - 1;
+        const int off0 = 32 * w + kb0 + 1, off1 = 32 * w + kb1 + 1;
+        const int oa = o0 + off0, ob = o0 + off1;
+        int jd0 = d + off0, jd1 = d + off1;
+        if (jd0 >= N) jd0 -= N;
+        if (jd1 >= N) jd1 -= N;
+        const int ja = el * N + jd0, jb = el * N + jd1;  // slots in the single-copy arrays
+#define RVO3D_LD2(K, i0, i1) ((v2f){L.w[K][i0], L.w[K][i1]})
+        // straight-line fp32; booleans are combined bitwise on purpose (no branches)
+        const v2f dx = RVO3D_LD2(WX, oa, ob) - mex2, dy = RVO3D_LD2(WY, oa, ob) - mey2,
+                  dz = RVO3D_LD2(WZ, oa, ob) - mez2;
+        const v2f jvx = RVO3D_LD2(WVX, ja, jb), jvy = RVO3D_LD2(WVY, ja, jb),
+                  jvz = RVO3D_LD2(WVZ, ja, jb);
+        const v2f jr = RVO3D_LD2(WR, oa, ob), jkd = RVO3D_LD2(WKD, ja, jb),
+                  jprio = RVO3D_LD2(WPRIO, ja, jb);
+        const v2f z2 = {0.f, 0.f};
+        const v2f ajx = zero_act ? z2 : RVO3D_LD2(WAX, ja, jb),
+                  ajy = zero_act ? z2 : RVO3D_LD2(WAY, ja, jb),
+                  ajz = zero_act ? z2 : RVO3D_LD2(WAZ, ja, jb);
+#undef RVO3D_LD2
+        const v2f d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
+        const v2f rs = jr + mer2;
+        const v2f rs2 = rs * rs;
+        const v2f tch = __builtin_elementwise_fma(rs2, (v2f){1.00001f, 1.00001f},
+                                                  (v2f){P.band, P.band});
+        // possibly approaching, each direction (v.rel > -eps)
+        const v2f vi = __builtin_elementwise_fma(
+            mvz2, dz, __builtin_elementwise_fma(mvy2, dy, mvx2 * dx));
+        const v2f vj = __builtin_elementwise_fma(
+            jvz, dz, __builtin_elementwise_fma(jvy, dy, jvx * dx));
+        // cone pre-filter: |ab| cos(alpha + 2e-3), slack x1_k2 on its square
+        const v2f gap = d2 - rs2;  // d^2 - R^2
+        // raw v_sqrt_f32 (1 ulp): the filter's slack covers it
+        const v2f sq_ = {__builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.x, 0.f)),
+                         __builtin_amdgcn_sqrtf(__builtin_fmaxf(gap.y, 0.f))};
+        // K <= 0: the second clause below is empty (its bound becomes 0)
+        const v2f Kr = (v2f){0.999998f, 0.999998f} * sq_ - (v2f){2.0e-3f, 2.0e-3f} * rs;
+        const v2f K = {__builtin_fmaxf(Kr.x, 0.f), __builtin_fmaxf(Kr.y, 0.f)};
+        const v2f K2 = K * K * (v2f){P.x1_k2, P.x1_k2};
+        const v2f hf = {0.5f, 0.5f};
+        const v2f hx = hf * (mvx2 + jvx), hy = hf * (mvy2 + jvy), hz = hf * (mvz2 + jvz);
+        // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
+        const v2f wix = tax - hx, wiy = tay - hy, wiz = taz - hz;
+        const v2f dpi = __builtin_elementwise_fma(
+            dz, wiz, __builtin_elementwise_fma(dy, wiy, dx * wix));
+        const v2f wi2 = __builtin_elementwise_fma(
+            wiz, wiz, __builtin_elementwise_fma(wiy, wiy, wix * wix));
+        // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
+        const v2f two2 = {2.f, 2.f};
+        const v2f wjx = two2 * ajx - hx, wjy = two2 * ajy - hy, wjz = two2 * ajz - hz;
+        const v2f dpj = -__builtin_elementwise_fma(
+            dz, wjz, __builtin_elementwise_fma(dy, wjy, dx * wjx));
+        const v2f wj2 = __builtin_elementwise_fma(
+            wjz, wjz, __builtin_elementwise_fma(wjy, wjy, wjx * wjx));
+        const v2f cs = (v2f){P.x1_cs2, P.x1_cs2} * d2;
+        // signed squares: s = dp |dp|.  Surely outside the cone: cos < -cs (s < -cs w2), or
+        // 0 <= cos < cos(alpha + delta) with slack (0 <= s < K^2 w2); one bound per sign of s
+        // and ONE comparison s < bound (a NaN compares false: the pair is kept).
+        const v2f si = dpi * __builtin_elementwise_abs(dpi), sj = dpj * __builtin_elementwise_abs(dpj);
+        const v2f ci = -(cs * wi2), cj = -(cs * wj2), ki = wi2 * K2, kj = wj2 * K2;
+#define RVO3D_X1_HALF(c, jd, pi, pj)                                                          \
+        {                                                                                     \
+          const int touch = TOUCH & (int)(d2.c <= tch.c);                                     \
+          const int ai = vi.c > -mkd, aj = vj.c < jkd.c;                                      \
+          const int filt = (int)(gap.c >= P.x1_gap) & (int)(jprio.c == mprio);                \
+          const int oi = si.c < (si.c < 0.f ? ci.c : ki.c);                                   \
+          const int oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                   \
+          pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
+          pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
+        }
+        bool pi0, pj0, pi1, pj1;
+        RVO3D_X1_HALF(x, jd0, pi0, pj0)
+        RVO3D_X1_HALF(y, jd1, pi1, pj1)
+#undef RVO3D_X1_HALF
+        pi1 &= two; pj1 &= two;
+        if (NW == 1) {
+          m2r |= ((unsigned long long)pi0 << jd0) | ((unsigned long long)pi1 << jd1);
+        } else {
+          if (pi0) atomicOr(&L.mask2[lane * NW + (jd0 >> 6)], 1ull << (jd0 & 63));
+          if (pi1) atomicOr(&L.mask2[lane * NW + (jd1 >> 6)], 1ull << (jd1 & 63));
+        }
+        if (pj0) atomicOr(&L.mask2[(el * N + jd0) * NW + (d >> 6)], 1ull << (d & 63));
+        if (pj1) atomicOr(&L.mask2[(el * N + jd1) * NW + (d >> 6)], 1ull << (d & 63));
+      }
+    }
+  }
+  if (ROWS && !TOUCH) RVO3D_STAMP(12);
+  if (!ROWS) RVO3D_STAMP(14);
+  __syncthreads();
+  if (active && !(P.ablate & 32)) {
+    const int lbase = el * N;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
+      while (m2) {  // stage X2: exact, requested pairs only
+        const int j = 64 * w + __builtin_ctzll(m2);
+        m2 &= m2 - 1;
+        const PairOut po = pair_eval(P, S, L, lbase + j, a);
+        if (TOUCH && po.collision) collision = true;
+        if (po.flag) {
+          flag = true;
+          if (po.t < tmin) tmin = po.t;
+          if (ROWS && P.nm > 0) kept = insert_row(P, L, g, lbase, S, po, j, kept);
+        }
+      }
+    }
+  }
+  if (ROWS && !TOUCH) RVO3D_STAMP(13);
+  if (!ROWS) RVO3D_STAMP(15);
+  return kept;
+}
+
+// Collision-only sweep: exactly the collision_flag part of rvo_inter.config_vo_inf
+// (rvo_inter.py:40-48) - a neighbour inside the 10 m gate, not at the very same
+// position, with dis <= r + mr (env_train) - for every drone of the env.  Each
+// unordered pair is tested once; the fp32 stage only selects pairs that are possibly
+// touching, the decision itself is fp64.
+template <int NW>
+__device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int lane, int el,
+                                            int d, bool active, const Drone& S,
+                                            uint32_t gw[NW]) {
+  const int N = P.N, H = N >> 1;
+  L.mask2[lane * NW] = 0ull;
+  __syncthreads();
+  bool coll = false;
+  if (active) {
+    const int o0 = el * 2 * N + d;
+    const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0], mer = L.w[WR][o0];
+    const bool far = L.far[el] != 0;
+    uint32_t valid[NW];
+    valid_offsets<NW>(N, d, valid);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      // one pass over the offsets: possibly touching (cand) and possibly in range (gw, the
+      // stage-G words of this post-move state for the rows sweep that follows)
+      uint32_t cand = valid[w];
+      gw[w] = valid[w];
+      if (!far) {
+        uint32_t rng;
+        cand = gate_word<true>(P, L, o0, w, H, mex, mey, mez, mer, &rng) & valid[w];
+        gw[w] = rng & valid[w];
+      }
+      while (cand) {  // exact decision, both drones of the pair
+        const int kb = __builtin_ctz(cand);
+        cand &= cand - 1;
+        int jd = d + 32 * w + kb + 1;
+        if (jd >= N) jd -= N;
+        const int k = el * N + jd;
+        const double rx = L.x[k] - S.x, ry = L.y[k] - S.y, rz = L.z[k] - S.z;
+        const double d2 = dot3b(rx, ry, rz, rx, ry, rz);
+        if (!(d2 <= P.T10)) continue;
+        if (d2 == 0.0 && rx == 0.0 && ry == 0.0 && rz == 0.0) continue;
+        const double Or = L.r[k];
+        const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
+        bool ci, cj;
+        if (P.env_train) {
+          ci = cj = dis <= S.r + Or;
+        } else {  // rvo_inter.py:145-147: r - exp_radius + mr, evaluated from each side
+          ci = dis <= S.r - kExpRadius + Or;
+          cj = dis <= Or - kExpRadius + S.r;
+        }
+        if (ci) coll = true;
+        if (cj) atomicOr(&L.mask2[k * NW], 1ull);
+      }
+    }
+  }
+  __syncthreads();
+  if (active && (L.mask2[lane * NW] & 1ull)) coll = true;
+  return coll;
+}
+
+// One-wave workgroups: bring the stage-G word of every drone up to date after the drones in
+// `reset_lanes` (ballot) moved to their start positions (fp32 image already restaged).  Only
+// pairs with a reset drone change: each reset drone r is tested against all lanes of its env
+// at once (same arithmetic as gate_word, so the bits equal a full recomputation); the pair's
+// owner - the end whose offset to the other is <= N/2 - takes the bit, and r itself rebuilds
+// its word from the ballot rotated to its own offset order.
+__device__ __forceinline__ uint32_t regate_resets(const Params& P, const Lds& L, int tid, int el,
+                                                  int d, bool active,
+                                                  unsigned long long reset_lanes, uint32_t gw) {
+  const int N = P.N, H = N >> 1;
+  uint32_t valid[1];
+  valid_offsets<1>(N, d, valid);
+  const int o0 = el * 2 * N + d;
+  const float mex = L.w[WX][o0], mey = L.w[WY][o0], mez = L.w[WZ][o0];
+  while (reset_lanes) {
+    const int rl = __builtin_ctzll(reset_lanes);
+    reset_lanes &= reset_lanes - 1;
+    const int rel = __builtin_amdgcn_readlane(el, rl), rd = __builtin_amdgcn_readlane(d, rl);
+    const int orr = rel * 2 * N + rd;
+    const float dx = L.w[WX][orr] - mex, dy = L.w[WY][orr] - mey, dz = L.w[WZ][orr] - mez;
+    float d2 = dx * dx;
+    d2 = __builtin_fmaf(dy, dy, d2);
+    d2 = __builtin_fmaf(dz, dz, d2);
+    const bool same = active && el == rel && tid != rl;
+    const bool inr = same && d2 <= P.t10f;
+    int k = rd - d;  // offset from me to r
+    if (k < 0) k += N;
+    if (same && k >= 1 && k <= H) {  // I own the pair (if the offset is mine at all)
+      const uint32_t bit = 1u << (k - 1);
+      gw = (gw & ~bit) | ((inr ? bit : 0u) & valid[0]);
+    }
+    const unsigned long long bal = __ballot(inr);
+    if (tid == rl) {
+      unsigned long long seg = bal >> (rel * N), rot;
+      if (N == 64) {
+        const int sh = (rd + 1) & 63;
+        rot = sh ? ((seg >> sh) | (seg << (64 - sh))) : seg;
+      } else {
+        seg &= (1ull << N) - 1ull;
+        const int sh = rd + 1;  // 1..N
+        rot = ((seg >> sh) | (seg << (N - sh))) & ((1ull << N) - 1ull);
+      }
+      gw = (uint32_t)rot & valid[0];
+    }
+  }
+  return gw;
+}
+
+}  // namespace rvo3d

@@ -1,0 +1,609 @@
+// rvo3d_step.hpp -- The environment step kernel and its per-drone parts: building gate, observation writers,
+// zero fill, rewards, env_kernel<MODE, NW>.
+// Part of the gfx950 device code (see rvo3d_device.hpp for the overview).
+#pragma once
+
+#include "rvo3d_pairs.hpp"
+
+namespace rvo3d {
+
+// building gate + check_col_with_budilding (rvo_inter.py:99-105, 198-209)
+__device__ __forceinline__ bool building_test(const double* const bld, int b, const Drone& S,
+                                              double T5) {
+  const double bx = bld[4 * b], by = bld[4 * b + 1], bh = bld[4 * b + 2], br = bld[4 * b + 3];
+  const double ex = S.x - bx, ey = S.y - by;
+  // h > z - 2 and norm <= 5 (gate), z <= h, then dis <= r + br on the few that pass
+  if ((bh > S.z - 2) & (norm2sq(ex, ey) <= T5) & (S.z <= bh))
+    return __builtin_sqrt(sq(ex) + sq(ey)) <= S.r + br;
+  return false;
+}
+__device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
+  const int nb = P.cold().nb;
+  if (nb == 0) return false;
+  bool hit = false;
+  const double* const bld = P.cold().bld;
+  const double T5 = P.cold().T5;
+  const int gx = P.cold().bgx;
+  if (gx > 0) {
+    // only the buildings listed for the drone's cell can pass the 5 m gate (the lists are
+    // conservative; a drone outside the map collides anyway and NaN passes no test)
+    const int gy = P.cold().bgy;
+    const double inv = P.cold().bg_inv;
+    int ix = (int)__builtin_floor(S.x * inv), iy = (int)__builtin_floor(S.y * inv);
+    ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
+    const uint16_t* const cell = P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1);
+    const int cnt = cell[0];
+    if (cnt != 0xffff) {
+      for (int k = 0; k < cnt; ++k) hit |= building_test(bld, cell[1 + k], S, T5);
+      return hit;
+    }
+  }
+#pragma unroll 4
+  for (int b = 0; b < nb; ++b) hit |= building_test(bld, b, S, T5);
+  return hit;
+}
+
+// Proprioceptive part of one observation row: np.round of [state, vel, radius,
+// priority, des_vel, deviation] (ir_gym.py:208-229 / :353-355), 12 floats.  The last four
+// arrive already rounded (`tail`, made by proprio_tail before the final sweep so that the
+// fp64 values are dead across it).
+struct ProprioTail { float dv0, dv1, dv2, dev; bool bad; };
+__device__ __forceinline__ ProprioTail proprio_tail(const double dv[3], double dev) {
+  ProprioTail t;
+  t.dv0 = round2_f32(dv[0]); t.dv1 = round2_f32(dv[1]); t.dv2 = round2_f32(dv[2]);
+  t.dev = round2_f32(dev);
+  t.bad = !(finite_d(dv[0]) && finite_d(dv[1]) && finite_d(dv[2]) && finite_d(dev));
+  return t;
+}
+__device__ __forceinline__ void write_proprio(const Params& P, int g, const Drone& S,
+                                              const ProprioTail& t) {
+  float* o = P.obs + (size_t)g * P.W;
+  const double v[8] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio};
+  float f[12];
+  bool bad = t.bad;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    f[k] = round2_f32(v[k]);
+    bad |= !finite_d(v[k]);
+  }
+  f[8] = t.dv0; f[9] = t.dv1; f[10] = t.dv2; f[11] = t.dev;
+  if ((P.W & 1) == 0) {  // rows are 8-B aligned
+    float2* o2 = reinterpret_cast<float2*>(o);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o2[k] = make_float2(f[2 * k], f[2 * k + 1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) o[k] = f[k];
+  }
+  if (bad) atomicOr(P.err, 1u);
+}
+
+// The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
+// iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
+// behind them (written by zero_fill()).
+__device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int tid, int lbase,
+                                              int g, const Drone& S, int kept) {
+  float* o = P.obs + (size_t)g * P.W;
+  bool bad = false;
+  for (int s = 0; s < kept; ++s) {
+    const uint32_t pk = P.row_pk(s)[g];
+    const int j = (int)(pk & 0xffffu);
+    const Drone O = lds_drone(L, lbase + j);
+    const double pr = (S.prio == O.prio) ? 0.5 : S.prio / (S.prio + O.prio);
+    double row[9];
+    row[0] = pr * (2 * S.x + (S.vx + O.vx));  // get_PAA, vel_obs3D.py:19-32
+    row[1] = pr * (2 * S.y + (S.vy + O.vy));
+    row[2] = pr * (2 * S.z + (S.vz + O.vz));
+    row[3] = O.x - S.x; row[4] = O.y - S.y; row[5] = O.z - S.z;
+    row[6] = (double)(pk >> 16) / 100.0;
+    row[7] = pair_md(S, O);
+    row[8] = P.row_iet(s)[g];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      bad |= !finite_d(row[k]);
+      o[12 + 9 * s + k] = round2_f32(row[k]);
+    }
+  }
+  // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
+  if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
+  if (P.zf16) {
+    // 16-B zero-fill: this lane writes the 8-B pieces that do not fill a 16-B chunk at
+    // either end of its zero run and publishes the run as a chunk range [c0, c1)
+    const unsigned long long rb = 4ull * (unsigned)P.W;
+    const unsigned long long row_b = rb * (unsigned long long)g;
+    unsigned long long zs = row_b + 4ull * (unsigned)((12 + 9 * kept + 1) & ~1);
+    unsigned long long ze = row_b + rb;
+    char* ob = reinterpret_cast<char*>(P.obs);
+    if (zs < ze && (zs & 8)) { *reinterpret_cast<float2*>(ob + zs) = make_float2(0.f, 0.f); zs += 8; }
+    if (zs < ze && (ze & 8)) { ze -= 8; *reinterpret_cast<float2*>(ob + ze) = make_float2(0.f, 0.f); }
+    if (zs > ze) zs = ze;
+    L.zc[2 * tid] = (uint32_t)(zs >> 4);
+    L.zc[2 * tid + 1] = (uint32_t)(ze >> 4);
+  }
+  P.vo_count[g] = kept;
+  if (bad) atomicOr(P.err, 1u);
+}
+
+// Cooperative, coalesced zero padding of the VO region of every row of this
+// workgroup: rows [row0, row0 + nrows) are contiguous in memory; L.kept holds
+// the kept count per row.  Unit = float2 when W is even (rows 8-B aligned),
+// float otherwise.
+__device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid, int row0,
+                                          int nrows) {
+  if (P.zf16) {
+    // rows [row0, row0 + nrows) occupy bytes [rb*row0, rb*(row0+nrows)); every 16-B chunk
+    // that starts inside a row's published zero run is stored, fully coalesced
+    const unsigned long long rb = 4ull * (unsigned)P.W;
+    const uint32_t cbeg = (uint32_t)((rb * (unsigned)row0 + 15) >> 4);
+    const uint32_t cend = (uint32_t)((rb * (unsigned)(row0 + nrows)) >> 4);
+    float4* ob = reinterpret_cast<float4*>(P.obs);
+    const uint2* zc2 = reinterpret_cast<const uint2*>(L.zc);
+    const unsigned long long m40 = P.cold().zf_m40;
+    // four chunks per trip: the run lookups (one 8-B LDS read each) are issued together
+    // and nothing in the body branches, so a trip costs one LDS round trip, not eight
+    for (uint32_t c = cbeg + tid; c < cend; c += 4 * L.T) {
+      uint2 z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t cu = c + u * L.T;
+        const uint32_t cc = cu < cend ? cu : c;  // clamp: the lookup stays inside this block
+        const uint32_t grow = (uint32_t)(((unsigned long long)(2u * cc) * m40) >> 40);
+        z[u] = zc2[grow - (uint32_t)row0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t cu = c + u * L.T;
+        if ((cu < cend) & (cu >= z[u].x) & (cu < z[u].y)) ob[cu] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    return;
+  }
+  const uint32_t per_row = P.cold().zf_div;
+  if (per_row == 0) return;
+  const uint32_t total = (uint32_t)nrows * per_row;
+  float* base = P.obs + (size_t)row0 * P.W + 12;
+  if ((P.W & 1) == 0) {
+    for (uint32_t q = tid; q < total; q += L.T) {
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.cold().zf_magic) >> 32);
+      const uint32_t c = q - row * per_row;       // float2 index inside the VO region
+      const uint32_t first = (9u * (uint32_t)L.kept[row] + 1u) >> 1;  // first all-zero unit
+      if (c >= first)
+        *reinterpret_cast<float2*>(base + (size_t)row * P.W + 2 * c) = make_float2(0.f, 0.f);
+    }
+  } else {
+    for (uint32_t q = tid; q < total; q += L.T) {
+      const uint32_t row = (uint32_t)(((uint64_t)q * P.cold().zf_magic) >> 32);
+      const uint32_t c = q - row * per_row;
+      if (c >= 9u * (uint32_t)L.kept[row]) base[(size_t)row * P.W + c] = 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ void load_wp(const Params& P, int g, int k, double out[3]) {
+  out[0] = P.wp(k, 0)[g];
+  out[1] = P.wp(k, 1)[g];
+  out[2] = P.wp(k, 2)[g];
+}
+
+__device__ __forceinline__ void load3(double* const a0, double* const a1, double* const a2, int g,
+                                      double out[3]) {
+  out[0] = a0[g]; out[1] = a1[g]; out[2] = a2[g];
+}
+__device__ __forceinline__ void store3(double* const a0, double* const a1, double* const a2, int g,
+                                       const double v[3]) {
+  a0[g] = v[0]; a1[g] = v[1]; a2[g] = v[2];
+}
+#define RVO3D_LOAD_CUR(P, g, out) load3((P).cur(0), (P).cur(1), (P).cur(2), g, out)
+#define RVO3D_LOAD_PREV(P, g, out) load3((P).prev(0), (P).prev(1), (P).prev(2), g, out)
+#define RVO3D_STORE_CUR(P, g, v) store3((P).cur(0), (P).cur(1), (P).cur(2), g, v)
+#define RVO3D_STORE_PREV(P, g, v) store3((P).prev(0), (P).prev(1), (P).prev(2), g, v)
+
+// ir_gym.rvo_reward_cal (ir_gym.py:64-133), the part that does not depend on the sweep:
+// angle_punish + vel_penalty.  The sweep's safety term is added afterwards in the
+// reference's order, (punish + vel_penalty) + safety: rvo_reward_k().
+__device__ __forceinline__ double rvo_reward_pre(const double dv[3], const double a[3]) {
+  // des_vel is already a 3-decimal value: np.round(., 3) again is the identity
+  const double d0 = dv[0], d1 = dv[1], d2 = dv[2];
+  const double vel_penalty = 0.2 * norm3b(a[0], a[1], a[2]) / norm3b(d0, d1, d2);
+  const double eps = 1e-8;
+  const double magA = __builtin_sqrt(sq(d0) + sq(d1) + sq(d2) + eps);
+  const double magB = __builtin_sqrt(sq(a[0]) + sq(a[1]) + sq(a[2]) + eps);
+  const double dotp = d0 * a[0] + d1 * a[1] + d2 * a[2];
+  double c = dotp / (magA * magB);  // magA, magB >= 1e-4: the `< 1e-6` branch is dead
+  c = c < -1.0 + eps ? -1.0 + eps : (c > 1.0 - eps ? 1.0 - eps : c);
+  // angle bins (ir_gym.py:91-100) on ang = acos(c): compare c with the cosines of
+  // the bin edges; acos itself only when c is within 1e-12 of an edge.
+  const double C18 = 0.984807753012208, C6 = 0.8660254037844387, C3 = 0.5000000000000001,
+               C2 = 6.123233995736766e-17;
+  double punish;
+  if (c == 0.0) punish = -4;  // acos(0) == pi/2 exactly: not < pi/2
+  else if (__builtin_fabs(c - C18) > 1e-12 && __builtin_fabs(c - C6) > 1e-12 &&
+           __builtin_fabs(c - C3) > 1e-12 && __builtin_fabs(c - C2) > 1e-12) {
+    punish = c > C18 ? 3 : (c > C6 ? 1 : (c > C3 ? 0.5 : (c > C2 ? 0 : -4)));
+    if (c != c) punish = -4;
+  } else {
+    const double ang = acos(c);
+    if (ang < kPi / 18) punish = 3;
+    else if (ang < kPi / 6) punish = 1;
+    else if (ang < kPi / 3) punish = 0.5;
+    else if (ang < kPi / 2) punish = 0;
+    else punish = -4;
+  }
+  return punish + vel_penalty;
+}
+// Returns the integer k with np.round(total, 3) == k / 1000 (or inf / nan, survey Q9).
+__device__ __forceinline__ double rvo_reward_k(double pre, bool flag, double tmin) {
+  double safety = 0;
+  if (flag) {
+    double urgency = 0;
+    if (tmin < 2) urgency = -8.0 * exp(-tmin / 0.5);
+    safety = -2.5 + urgency;
+  }
+  return __builtin_rint((pre + safety) * 1000.0);
+}
+
+// ir_gym.mov_reward (ir_gym.py:256-311); returns k with round(., 3) == k / 1000
+__device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, bool arrive_r,
+                                               int waypoint_num, int n_points_m1, bool dest_r,
+                                               double dev, bool len_flag, double exlen) {
+  if (collision) return -50000.0;  // -50
+  double reward = 0;
+  if (arrive_r) reward += 3.0 * P.cold().pow95[n_points_m1 - waypoint_num];
+  if (dest_r) reward += 20.0;
+  const double d = dev * 10;
+  const double dev_pen = -1.5 * (2 / (1 + exp(-(d - 5) / 0.3)));
+  double ex_pen = 0;
+  if (len_flag) {
+    ex_pen = -0.3 * log(exlen + 1 + 1e-6);
+    if (ex_pen < -6 || ex_pen != ex_pen) ex_pen = -6;
+  }
+  return __builtin_rint((reward + dev_pen + ex_pen) * 1000.0);
+}
+
+// mdin.py:28 adds two np.round(., 3) values in fp64; k / 1000 is formed exactly
+// (k_over_1000) so the sum, cancellation included, is the reference's double.
+__device__ __forceinline__ float reward_f32(double k1, double k2) {
+  return (float)(k_over_1000(k1) + k_over_1000(k2));
+}
+
+enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
+
+// One-wave workgroups (N <= 64) are register-limited: 128 VGPRs = 4 waves per SIMD, i.e. the
+// 4096 waves of 64 x 4096 are all resident at once.  Larger N is LDS-limited (3 per SIMD).
+#ifndef RVO3D_WAVES_ATTR
+#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NW == 1 ? 4 : 3)))
+#endif
+
+// The whole environment step, one launch.
+template <int MODE, int NW>
+__global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, T = NW == 1 ? 64 : (int)blockDim.x, N = P.N;
+  const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
+  const int el = tid / N;
+  const int d = tid - el * N;
+  const int e0 = blockIdx.x * P.epb;
+  const int e = e0 + el;
+  const bool active = (el < P.epb) && (e < P.E);
+  const int g = active ? e * N + d : 0;
+  const int lbase = el * N;
+  const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
+  constexpr bool LITE = (MODE == kStepAutoReset);
+
+  // Register discipline: values are loaded right before the phase that needs them and
+  // stored as soon as they are final, so that across the sweeps little more than the
+  // drone's own 8-value record and its action stay live (registers = waves per SIMD).
+  RVO3D_STAMP(0);
+  Drone S;
+  S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;
+  double a[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
+  double dev = 0, max_dev = 0;
+  int wpi = 1;
+
+  // ---- phase 0: the drone's own record and its action; everything else about the pre-move
+  //      state (waypoints, des_vel, deviation) is fetched after sweep A, which needs none of it
+  if (active) {
+    S.x = P.px()[g]; S.y = P.py()[g]; S.z = P.pz()[g];
+    S.vx = P.vx()[g]; S.vy = P.vy()[g]; S.vz = P.vz()[g];
+    S.r = P.radius()[g]; S.prio = P.prio()[g];
+    if (MODE != kObserve) {
+      if (P.action_mode == 1) {
+        // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:
+        //   a_inc = np.round(sample, 2)                  float32: rint(a * 100f) / 100f
+        //   abs   = np.round(acceler * a_inc + vel, 2)   float32 product, widened, + float64
+        const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
+        const double vv[3] = {S.vx, S.vy, S.vz};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float r = __builtin_rintf(A[k] * 100.0f) / 100.0f;
+          const double x = (double)(P.acceler * r) + vv[k];
+          a[k] = __builtin_rint(x * 100.0) / 100.0;
+        }
+      } else {
+        if (P.action_f64) {
+          const double* A = static_cast<const double*>(P.actions) + (size_t)g * 3;
+          a[0] = A[0]; a[1] = A[1]; a[2] = A[2];
+        } else {
+          const float* A = static_cast<const float*>(P.actions) + (size_t)g * 3;
+          a[0] = (double)A[0]; a[1] = (double)A[1]; a[2] = (double)A[2];
+        }
+        if (P.cold().act_scale > 0) {
+          a[0] = __builtin_rint(a[0] * P.cold().act_scale) / P.cold().act_scale;
+          a[1] = __builtin_rint(a[1] * P.cold().act_scale) / P.cold().act_scale;
+          a[2] = __builtin_rint(a[2] * P.cold().act_scale) / P.cold().act_scale;
+        }
+      }
+    }
+  }
+  RVO3D_STAMP(1);
+  double az[3] = {a[0], a[1], a[2]};  // action as the RVO code sees it (rvo_inter.py:118)
+  if (norm3b(a[0], a[1], a[2]) < 1e-5) az[0] = az[1] = az[2] = 0.0;
+  const double zero3[3] = {0, 0, 0};
+
+  if (tid < P.epb) { L.any_reset[tid] = 0; L.far[tid] = 0; }
+  L.kept[tid] = 0;
+  __syncthreads();  // flags zeroed before anyone raises them
+  L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
+  L.vx[tid] = S.vx; L.vy[tid] = S.vy; L.vz[tid] = S.vz;
+  L.r[tid] = S.r; L.prio[tid] = S.prio;
+  {
+    const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
+    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+  }
+  __syncthreads();
+
+  bool flag, collision = false;
+  double tmin;
+
+  if (MODE == kObserve) {
+    if (active) {  // drone.dronestate (drone.py:254-263)
+      double prev[3];
+      max_dev = P.max_dev()[g];
+      RVO3D_LOAD_CUR(P, g, cur);
+      RVO3D_LOAD_PREV(P, g, prev);
+      const double p[3] = {S.x, S.y, S.z};
+      des_vel(P, p, cur, dv);
+      dev = deviation(prev, cur, p);
+      if (dev > max_dev) max_dev = dev;
+    }
+    uint32_t gw[NW];
+    const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
+                                               tmin, collision, gw, false);
+    if (active) {
+      write_proprio(P, g, S, proprio_tail(dv, dev));
+      write_vo_rows(P, L, tid, lbase, g, S, kept);
+      L.kept[tid] = kept;
+      P.max_dev()[g] = max_dev;
+      uint32_t dvk_a, dvk_b;
+      dv_encode(dv, dvk_a, dvk_b);
+      P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
+    }
+    __syncthreads();
+    zero_fill(P, L, tid, e0 * N, nrows);
+    return;
+  }
+
+  RVO3D_STAMP(2);
+  // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
+  uint32_t gw[NW];
+  const bool have_gw = P.g_cached != 0;  // the previous step ended in this very state
+  if (have_gw && active) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
+  }
+  sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
+                              tmin, collision, gw, have_gw);
+  // ---- everything else about this drone arrives in ONE batch of loads now (none of the
+  //      addresses depends on a loaded value), then: drone.dronestate on the pre-move state
+  //      (drone.py:254-263) and the RVO reward - the state is the one the previous step (or
+  //      observe / reset) ended in, so its des_vel is on file and its deviation is already in
+  //      max_deviation; only a state set from outside is recomputed - and
+  //      drone.move_forward + kinematicstep (drone.py:96-129, 435-490), the post-move
+  //      dronestate and the arrival flags of ir_gym.observation_reward (:168-193)
+  double rew_k = 0;
+  double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
+  bool f_dest = false;
+  RVO3D_STAMP(3);
+  if (active) {
+    max_dev = P.max_dev()[g];
+    RVO3D_LOAD_CUR(P, g, cur);
+    bool have = false;
+    if (P.dv_cached) have = dv_decode(P.dvk_a()[g], P.dvk_b()[g], dv);
+    if (!have) {
+      double prev[3];
+      RVO3D_LOAD_PREV(P, g, prev);
+      const double p[3] = {S.x, S.y, S.z};
+      des_vel(P, p, cur, dv);
+      dev = deviation(prev, cur, p);
+      if (dev > max_dev) max_dev = dev;
+    }
+    rew_k = rvo_reward_k(rvo_reward_pre(dv, a), flag, tmin);
+  }
+  __syncthreads();  // everyone is done with the pre-move LDS image
+  if (active) {
+    double prev[3];
+    wpi = P.wp_idx()[g];
+    RVO3D_LOAD_PREV(P, g, prev);
+    double yaw = P.yaw()[g], pitch = P.pitch()[g], real_len = P.real_len()[g];
+    double extra_len = P.extra_len()[g];
+    const double route_len = P.route_len()[g];
+    const int npts = P.n_points()[g];
+    bool f_arrive = P.arrive()[g] != 0;
+    f_dest = P.dest()[g] != 0;
+
+    double speed = norm3b(S.vx, S.vy, S.vz);
+    const double acc = clampd(a[0] * 1.0, -1.0, 1.0);
+    const double dyaw = clampd(a[1] * 90.0, -90.0, 90.0);
+    const double dpit = clampd(a[2] * 90.0, -90.0, 90.0);
+    const double nv = speed + acc;
+    speed = (0.0 > nv) ? 0.0 : nv;
+    yaw = np_mod(yaw + dyaw, 360.0);
+    pitch = clampd(pitch + dpit, -90.0, 90.0);
+    double nvx = 0.0, nvy = 0.0, nvz = 0.0;
+    if (!f_dest) {  // `stop` := map_size (env_base.py:142, drone.py:107): parked once finished
+      double sy, cy, sp, cp;
+      sincos(yaw * kDeg2Rad, &sy, &cy);
+      sincos(pitch * kDeg2Rad, &sp, &cp);
+      nvx = speed * cp * cy; nvy = speed * cp * sy; nvz = speed * sp;
+    }
+    const double q0 = S.x, q1 = S.y, q2 = S.z;
+    S.x = S.x + nvx; S.y = S.y + nvy; S.z = S.z + nvz;
+    S.vx = nvx; S.vy = nvy; S.vz = nvz;
+    real_len = real_len + norm3b(S.x - q0, S.y - q1, S.z - q2);
+    const double p[3] = {S.x, S.y, S.z};
+    // the destination matters only next to a waypoint: fetched on demand (rare)
+    double dst[3] = {0, 0, 0};
+    if (f_arrive || arrived(P, p, cur)) load_wp(P, g, npts - 1, dst);
+    if (arrived(P, p, cur)) {  // drone.py:116-129
+      const bool at_dst = arrived(P, p, dst);
+      if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
+      if (!at_dst && wpi < npts - 1) {
+        wpi += 1;
+        prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
+        load_wp(P, g, wpi, cur);
+        RVO3D_STORE_CUR(P, g, cur);
+        RVO3D_STORE_PREV(P, g, prev);
+        f_arrive = false;
+      }
+    }
+    // dronestate on the post-move state
+    des_vel(P, p, cur, dv);
+    dev = deviation(prev, cur, p);
+    if (dev > max_dev) max_dev = dev;
+    // arrival flags (ir_gym.py:168-181)
+    bool arrive_r = false, dest_r = false;
+    const int waypoint_num = wpi;
+    if (!f_arrive && arrived(P, p, cur)) { f_arrive = true; arrive_r = true; }
+    if (f_arrive) {
+      if (arrived(P, p, dst)) {
+        extra_len = real_len - route_len;
+        if (!f_dest) { f_dest = true; dest_r = true; }
+      }
+    }
+    const double exlen = real_len - route_len + 4;
+    mov_nc = mov_reward_k(P, false, arrive_r, waypoint_num, npts - 1, dest_r, dev, exlen > 0,
+                          exlen);
+    collision = building_hit(P, S);
+    if (S.x < 0 || S.x > P.cold().map[0] || S.y < 0 || S.y > P.cold().map[1] || S.z < 0 || S.z > P.cold().map[2])
+      collision = true;  // drone.drone_out_map, drone.py:213-225
+    // final for this step unless the drone is reset below
+    P.yaw()[g] = yaw; P.pitch()[g] = pitch; P.real_len()[g] = real_len; P.extra_len()[g] = extra_len;
+    P.wp_idx()[g] = wpi;
+    P.arrive()[g] = f_arrive ? 1 : 0; P.dest()[g] = f_dest ? 1 : 0;
+    P.info[g] = f_arrive ? 1 : 0;
+    P.finish[g] = f_dest ? 1 : 0;
+  }
+  L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
+  L.vx[tid] = S.vx; L.vy[tid] = S.vy; L.vz[tid] = S.vz;
+  {
+    const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
+    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+  }
+  __syncthreads();
+
+  RVO3D_STAMP(4);
+  // ---- sweep B: the pair part of ir_gym.observation_reward (ir_gym.py:197).
+  // In the fused auto-reset step an env that resets discards the step's VO rows (its
+  // observation is recomputed after the reset), so a collision-only sweep runs first,
+  // the resets are settled, and then ONE sweep produces the rows - on the post-move
+  // state with the action, or on the post-reset state with action 0.
+  int kept = 0;
+  if (LITE) {
+    if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S, gw)) collision = true;
+  } else {
+    kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
+                                     flag, tmin, collision, gw, false);
+  }
+  bool do_reset = false;
+  if (active) {
+    P.reward[g] = reward_f32(rew_k, collision ? -50000.0 : mov_nc);  // mdin.py:28
+    P.done[g] = collision ? 1 : 0;
+    do_reset = LITE && (collision || f_dest);
+  }
+
+  RVO3D_STAMP(5);
+  if (LITE) {
+    if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
+    if (do_reset) L.any_reset[el] = 1;
+    __syncthreads();  // sweep reads done; any_reset visible
+    if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
+      double p[3];
+      load_wp(P, g, 0, p);
+      S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
+      // dronestate of the start state: static, tabulated by rvo3d_load_world (dv0_kernel)
+      dev = P.dev0()[g];
+      load_wp(P, g, 1, cur);
+      if (!dv_decode(P.dv0_a()[g], P.dv0_b()[g], dv)) {
+        des_vel(P, p, cur, dv);
+        dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
+      }
+      RVO3D_STORE_CUR(P, g, cur);
+      RVO3D_STORE_PREV(P, g, p);
+      max_dev = dev > 0.0 ? dev : 0.0;
+      P.wp_idx()[g] = 1; P.arrive()[g] = 0; P.dest()[g] = 0;
+      P.real_len()[g] = 0.0; P.yaw()[g] = 0.0; P.pitch()[g] = 0.0;
+      L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
+      L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
+      const double v0[3] = {0, 0, 0};
+      stage_f32(P, L, el, d, true, p, v0, az, S.r, S.prio);
+    }
+  }
+  // everything about this drone except its VO rows is final now.  The stores wait until
+  // after the last sweep (vector memory returns in order: a load behind a store waits for
+  // it, and measured: stores issued here cost 1.5 %); the drone's record and the rounded
+  // floats of des_vel / deviation stay live across the sweep.
+  if (active) {
+    uint32_t dvk_a, dvk_b;
+    dv_encode(dv, dvk_a, dvk_b);  // des_vel, on file for the next step
+    P.dvk_a()[g] = dvk_a; P.dvk_b()[g] = dvk_b;
+  }
+  const ProprioTail ptail = proprio_tail(dv, dev);
+  if (LITE) {
+    __syncthreads();
+    RVO3D_STAMP(6);
+    // rows for every env: ir_gym.observation_reward's VO part (the env kept its state) or
+    // ir_gym.env_observation with action 0 (the env reset a drone, ir_gym.py:372-383)
+    const bool env_reset = active && (L.any_reset[el] != 0);
+    bool c2 = false;
+    const double* aa = env_reset ? zero3 : az;
+    // stage G: the collision sweep delivered the words of the post-move state; only pairs
+    // with a reset drone changed since (larger envs: recompute when the env reset anyone)
+    bool have_gw2 = !env_reset;
+    if (NW == 1) {
+      const unsigned long long rlanes = __ballot(do_reset);
+      if (L.far[el] != 0) {
+        uint32_t valid[1];
+        valid_offsets<1>(N, d, valid);
+        gw[0] = valid[0];
+      } else {
+        gw[0] = regate_resets(P, L, tid, el, d, active, rlanes, gw[0]);
+      }
+      have_gw2 = true;
+    }
+    if (P.ablate & 2) have_gw2 = false;  // diagnostics: the collision sweep was skipped
+    kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
+                                      env_reset, flag, tmin, c2, gw, have_gw2);
+  }
+  RVO3D_STAMP(7);
+  if (active) {
+    if (!(P.ablate & 8)) {
+      write_vo_rows(P, L, tid, lbase, g, S, kept);
+      write_proprio(P, g, S, ptail);
+    }
+    L.kept[tid] = kept;
+    P.max_dev()[g] = max_dev;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
+    P.px()[g] = S.x; P.py()[g] = S.y; P.pz()[g] = S.z;
+    P.vx()[g] = S.vx; P.vy()[g] = S.vy; P.vz()[g] = S.vz;
+  }
+  __syncthreads();  // L.kept complete
+  RVO3D_STAMP(8);
+  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
+  RVO3D_STAMP(9);
+}
+
+}  // namespace rvo3d

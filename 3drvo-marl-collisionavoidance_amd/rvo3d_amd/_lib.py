@@ -29,8 +29,8 @@ def lib_path() -> str:
 
 
 def sources():
-    return [os.path.join(_CSRC, "rvo3d_capi.hip"), os.path.join(_CSRC, "rvo3d_device.hpp"),
-            os.path.join(_ROOT, "include", "rvo3d.h")]
+    hpp = sorted(os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hpp"))
+    return [os.path.join(_CSRC, "rvo3d_capi.hip")] + hpp + [os.path.join(_ROOT, "include", "rvo3d.h")]
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:

@@ -1,5 +1,5 @@
 """Host-side proofs-by-enumeration of the arithmetic shortcuts the HIP kernel
-uses in place of the reference's literal operations (csrc/rvo3d_device.hpp).
+uses in place of the reference's literal operations (csrc/rvo3d_math.hpp, rvo3d_pairs.hpp).
 Each must be EXACTLY equivalent, not just close."""
 import ctypes
 import math
