@@ -176,7 +176,7 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_drone_step": B},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported once, at N = 1
             out["cpu_baseline"] = cpu_baseline(N, nm, tuple(args.map))
         print(json.dumps(out), flush=True)
     env.close()
