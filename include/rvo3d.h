@@ -63,8 +63,8 @@ typedef struct rvo3d_config {
   double map_size[3];     /* data_1.json "map_size"                            */
 } rvo3d_config;
 
-/* Device views of the handle's struct-of-arrays state, each [E*N]. Valid
- * until rvo3d_destroy. (reach-through used by the trainer: drone_list[i].vel,
+/* Device views (read-only, see rvo3d_state_ptrs) of the handle's struct-of-arrays state,
+ * each [E*N]. Valid until rvo3d_destroy. (reach-through used by the trainer: drone_list[i].vel,
  * multi_ppo.py:202; indicators_*, ir_gym.py:414-420) */
 typedef struct rvo3d_state_view {
   double *px, *py, *pz;       /* drone.state                                   */
@@ -149,7 +149,10 @@ int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
 int rvo3d_rvo_vel(rvo3d_env *h, const double *vmax, double acceler, double *out_vel,
                   void *stream);
 
-/* Zero-copy views of the state arrays. */
+/* Zero-copy views of the state arrays, READ-ONLY: the step keeps values derived from the
+ * state on file between calls (des_vel, the in-range words of the pair gate, the current /
+ * previous waypoint); state is changed through rvo3d_set_state / rvo3d_reset*, which bring
+ * them up to date or mark them stale. */
 int rvo3d_state_ptrs(rvo3d_env *h, rvo3d_state_view *out);
 /* Array-of-structs copies: pos/vel [E][N][3] f64, the rest [E][N]; any
  * pointer may be NULL.  set_state is for tests and checkpoint restore. */
