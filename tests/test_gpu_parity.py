@@ -425,3 +425,42 @@ def test_post_train_policy_test_matches_a_sequential_restatement():
     assert got["ep_len"] == lens
     np.testing.assert_allclose(got["speed"], speeds, rtol=1e-12)
     assert got["average_speed"] == float(np.round(np.mean(speeds), 2))
+
+
+@pytest.mark.parametrize("E,N,nb,size", [(4096, 64, 0, (50.0, 50.0, 10.0)),
+                                         (1024, 256, 50, (100.0, 100.0, 10.0))])
+def test_full_size_launch_matches_oracle_on_sampled_envs(E, N, nb, size):
+    """BASELINE configs 3 and 5 at their FULL sizes.  Environments never interact, so a
+    random sample of envs of the full-size run must equal the oracle run on exactly those
+    envs (same worlds, same actions): every output of every sampled drone, 6 fused steps."""
+    T = 6
+    world = synthetic_world(E, N, size, nb=nb)
+    rng = np.random.default_rng(11)
+    pick = np.sort(rng.choice(E, size=24 if N == 64 else 6, replace=False))
+    env = BatchedDroneEnv(world, neighbors_num=10, action_decimals=2)
+    sub = type(world)(world.waypoints[pick], world.n_points[pick], world.map_size, world.buildings)
+    ref = orc.OracleEnv(sub.waypoints, sub.n_points, sub.map_size, sub.buildings, nm=10, threads=8)
+    o0, c0 = env.observe(); r0, rc0 = ref.observe()
+    tl = Tally()
+    tl.check("obs0", eq_nan(o0.cpu().numpy()[pick], r0.astype(np.float32)), ref.margin())
+    for t in range(T):
+        a = synthetic_actions(E, N, t)
+        obs, cnt, rew, done, info, fin = env.step(torch.from_numpy(a.astype(np.float32)).cuda(), autoreset=True)
+        ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(a[pick])
+        mg = ref.margin()
+        tl.count(mg)
+        tl.check(f"reset_mask t={t}", env.reset_mask.cpu().numpy()[pick] == rm, mg)
+        tl.check(f"done t={t}", done.cpu().numpy()[pick] == rd, mg)
+        tl.check(f"info t={t}", info.cpu().numpy()[pick] == ri, mg)
+        tl.check(f"finish t={t}", fin.cpu().numpy()[pick] == rf, mg)
+        tl.check(f"vo_count t={t}", cnt.cpu().numpy()[pick] == rcnt, mg)
+        tl.check(f"obs f32-exact t={t}", eq_nan(obs.cpu().numpy()[pick], ro.astype(np.float32)), mg)
+        tl.check(f"reward f32-exact t={t}", eq_nan(rew.cpu().numpy()[pick], rr.astype(np.float32)), mg)
+    # whole-batch invariants of the padded observation: rows beyond vo_count are zero
+    o, c = obs.cpu().numpy(), cnt.cpu().numpy()
+    rows = o[:, :, 12:].reshape(E, N, 10, 9)
+    beyond = np.arange(10)[None, None, :] >= np.maximum(c, 0)[:, :, None]
+    assert not np.any(rows[beyond] != 0)
+    assert env.error_flags() == (1 if ref.nan_count else 0)
+    env.close()
+    print(tl.finish())

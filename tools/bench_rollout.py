@@ -16,6 +16,7 @@ ap.add_argument("--steps", type=int, default=16)
 ap.add_argument("--policy", default="mlp")
 ap.add_argument("--minibatch", type=int, default=262144)
 ap.add_argument("--amp", action="store_true")
+ap.add_argument("--no-update", action="store_true", help="rollout only (for profiling the loop)")
 args = ap.parse_args()
 E, N, T = args.envs, args.drones, args.steps
 env = BatchedDroneEnv(synthetic_world(E, N, (50, 50, 10)))
@@ -37,7 +38,8 @@ tr.collect()
 torch.cuda.synchronize(); t1 = time.perf_counter()
 data = tr.buf.get()
 torch.cuda.synchronize(); t2 = time.perf_counter()
-tr.update(data)
+if not args.no_update:
+    tr.update(data)
 torch.cuda.synchronize(); t3 = time.perf_counter()
 print(json.dumps({"policy": args.policy, "amp": args.amp, "envs": E, "drones": N, "steps": T,
                   "rollout_drone_steps_per_s": E * N * T / (t1 - t0),
