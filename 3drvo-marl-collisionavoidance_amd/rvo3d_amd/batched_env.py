@@ -112,20 +112,21 @@ class BatchedDroneEnv:
         self._last_actions = a  # keep the borrowed buffer alive until the launch ran
         return self.obs, self.vo_count, self.reward, self.done, self.info, self.finish
 
-    def step_policy(self, a_inc, autoreset: bool = True):
+    def step_policy(self, a_inc, autoreset: bool = True, obs_out=None, cnt_out=None):
         """Step from raw policy samples: the trainer's glue (multi_ppo.py:196-210,
         a = round(a_inc, 2); action = round(acceler * a + vel, 2)) runs on the device.
         a_inc: float32 [E, N, 3]."""
         a = torch.as_tensor(a_inc, device=self.device).to(torch.float32).contiguous()
         if tuple(a.shape) != (self.E, self.N, 3):
             raise AssertionError(f"a_inc must have shape ({self.E}, {self.N}, 3)")
+        o, c = self._outs(obs_out, cnt_out)
         rc = _lib.lib().rvo3d_step_policy(
-            self._h, _ptr(a), C.c_float(self.acceler), _ptr(self.obs), _ptr(self.vo_count),
+            self._h, _ptr(a), C.c_float(self.acceler), _ptr(o), _ptr(c),
             _ptr(self.reward), _ptr(self.done), _ptr(self.info), _ptr(self.finish),
             _ptr(self.reset_mask), 1 if autoreset else 0, self._stream())
         _lib.check(rc, "rvo3d_step_policy")
         self._last_actions = a
-        return self.obs, self.vo_count, self.reward, self.done, self.info, self.finish
+        return o, c, self.reward, self.done, self.info, self.finish
 
     def reset(self, env_mask=None):
         m = None
@@ -141,10 +142,21 @@ class BatchedDroneEnv:
                    "rvo3d_reset_drones")
         self._keep = m
 
-    def observe(self):
-        _lib.check(_lib.lib().rvo3d_observe(self._h, _ptr(self.obs), _ptr(self.vo_count),
-                                            self._stream()), "rvo3d_observe")
-        return self.obs, self.vo_count
+    def _outs(self, obs_out, cnt_out):
+        """Observation outputs: the env's own tensors, or caller-provided ones (e.g. the next
+        slot of a rollout buffer: the kernel writes there directly, nothing is copied)."""
+        if obs_out is None:
+            return self.obs, self.vo_count
+        if (obs_out.dtype != torch.float32 or cnt_out.dtype != torch.int32 or not obs_out.is_contiguous()
+                or not cnt_out.is_contiguous() or tuple(obs_out.shape) != (self.E, self.N, self.W)
+                or tuple(cnt_out.shape) != (self.E, self.N) or obs_out.device != self.device):
+            raise AssertionError("obs_out / cnt_out must be contiguous float32 [E,N,W] / int32 [E,N] on the env's device")
+        return obs_out, cnt_out
+
+    def observe(self, obs_out=None, cnt_out=None):
+        o, c = self._outs(obs_out, cnt_out)
+        _lib.check(_lib.lib().rvo3d_observe(self._h, _ptr(o), _ptr(c), self._stream()), "rvo3d_observe")
+        return o, c
 
     def des_vel(self):
         out = torch.empty((self.E, self.N, 3), dtype=torch.float64, device=self.device)

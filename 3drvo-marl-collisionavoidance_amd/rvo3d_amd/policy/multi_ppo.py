@@ -62,8 +62,10 @@ class RolloutBuffer:
 
     def __init__(self, T, E, N, obs_width, act_dim, device, gamma=0.99, lam=0.95):
         f32 = dict(dtype=torch.float32, device=device)
-        self.obs = torch.zeros((T, E, N, obs_width), **f32)
-        self.cnt = torch.zeros((T, E, N), dtype=torch.int32, device=device)
+        # T + 1 observation slots: slot t is what the policy saw at step t; the env writes the
+        # observation after step t straight into slot t + 1 (no copies in the rollout loop)
+        self.obs = torch.zeros((T + 1, E, N, obs_width), **f32)
+        self.cnt = torch.zeros((T + 1, E, N), dtype=torch.int32, device=device)
         self.act = torch.zeros((T, E, N, act_dim), **f32)
         self.rew = torch.zeros((T, E, N), **f32)
         self.val = torch.zeros((T, E, N), **f32)
@@ -74,7 +76,9 @@ class RolloutBuffer:
     def store(self, obs, cnt, act, rew, val, logp):
         assert self.ptr < self.T  # multi_ppo.py:59
         t = self.ptr
-        self.obs[t].copy_(obs); self.cnt[t].copy_(cnt); self.act[t].copy_(act)
+        if obs is not None and obs.data_ptr() != self.obs[t].data_ptr():
+            self.obs[t].copy_(obs); self.cnt[t].copy_(cnt)
+        self.act[t].copy_(act)
         self.rew[t].copy_(rew); self.val[t].copy_(val); self.logp[t].copy_(logp)
         self.ptr += 1
 
@@ -89,8 +93,8 @@ class RolloutBuffer:
         self.ptr = 0
         self.cut.zero_()
         flat = lambda x: x.reshape((-1,) + x.shape[3:])
-        return dict(obs=flat(self.obs), cnt=flat(self.cnt), act=flat(self.act), ret=flat(ret),
-                    adv=flat(adv), logp=flat(self.logp))
+        return dict(obs=flat(self.obs[:self.T]), cnt=flat(self.cnt[:self.T]), act=flat(self.act),
+                    ret=flat(ret), adv=flat(adv), logp=flat(self.logp))
 
 
 class multi_ppo:
@@ -138,46 +142,54 @@ class multi_ppo:
 
     # ---- rollout ------------------------------------------------------------------------
     def collect(self):
-        """One epoch of steps_per_epoch env steps (multi_ppo.py:183-281), on the device."""
+        """One epoch of steps_per_epoch env steps (multi_ppo.py:183-281), on the device.  The
+        env writes each observation straight into the next buffer slot; the policy GEMMs run
+        under ONE autocast region (weight casts are cached across the steps)."""
         env, buf = self.env, self.buf
-        obs, cnt = env.obs, env.vo_count
+        cur_obs, cur_cnt = getattr(self, "_cur", (env.obs, env.vo_count))
+        buf.obs[0].copy_(cur_obs); buf.cnt[0].copy_(cur_cnt)
         ret_sum = torch.zeros((), device=self.device)
         ret_n = torch.zeros((), device=self.device)
-        for t in range(self.steps_per_epoch):
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp):
+        since_full_reset = 0  # no episode can be longer than this: timeouts need no device check before
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp):
+            for t in range(self.steps_per_epoch):
+                obs, cnt = buf.obs[t], buf.cnt[t]
                 a, v, logp = self.ac.step_tensors((obs.view(-1, env.W), cnt.view(-1)))
-            a, v, logp = a.float(), v.float(), logp.float()
-            a = a.view(self.E, self.N, 3)
-            prev_obs, prev_cnt = obs.clone(), cnt.clone()
-            # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
-            # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
-            obs, cnt, rew, done, info, fin = env.step_policy(a, autoreset=True)
-            # what the reference stores (multi_ppo.py:197): rint(a * 100) / 100 in float32 with a
-            # true division (a scalar divisor would become a multiplication by 1/100)
-            a_inc = torch.round(a * 100.0) / torch.full_like(a, 100.0)
-            if self.sanitize_rewards:
-                rew = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
-            buf.store(prev_obs, prev_cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))
-            self.ep_ret += torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
-            self.ep_len += 1
-            finb, doneb = fin.bool(), done.bool()
-            timeout = self.ep_len > self.max_ep_len
-            epoch_ended = t == self.steps_per_epoch - 1
-            terminal = (finb | timeout).any(dim=1)  # any drone of the env (multi_ppo.py:229)
-            ended = doneb | finb | timeout
-            ret_sum += (self.ep_ret * ended).sum()
-            ret_n += ended.sum()
-            extra = timeout & ~(doneb | finb)  # not yet reset by the fused step
-            if epoch_ended:
-                extra = ~(doneb | finb)         # full reset (multi_ppo.py:244-264)
-                terminal = torch.ones_like(terminal)
-                ended = torch.ones_like(ended)
-            if epoch_ended or bool(extra.any()):
-                env.reset_drones(extra)
-                obs, cnt = env.observe()
-            buf.finish_path(terminal)
-            self.ep_ret = torch.where(ended, torch.zeros_like(self.ep_ret), self.ep_ret)
-            self.ep_len = torch.where(ended, torch.zeros_like(self.ep_len), self.ep_len)
+                a, v, logp = a.float(), v.float(), logp.float()
+                a = a.view(self.E, self.N, 3)
+                # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
+                # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
+                _, _, rew, done, info, fin = env.step_policy(a, autoreset=True, obs_out=buf.obs[t + 1],
+                                                             cnt_out=buf.cnt[t + 1])
+                # what the reference stores (multi_ppo.py:197): rint(a * 100) / 100 in float32 with a
+                # true division (a scalar divisor would become a multiplication by 1/100)
+                a_inc = torch.round(a * 100.0) / torch.full_like(a, 100.0)
+                if self.sanitize_rewards:
+                    rew = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+                buf.store(obs, cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))
+                self.ep_ret += torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+                self.ep_len += 1
+                since_full_reset += 1
+                finb, doneb = fin.bool(), done.bool()
+                timeout = self.ep_len > self.max_ep_len
+                epoch_ended = t == self.steps_per_epoch - 1
+                terminal = (finb | timeout).any(dim=1)  # any drone of the env (multi_ppo.py:229)
+                ended = doneb | finb | timeout
+                ret_sum += (self.ep_ret * ended).sum()
+                ret_n += ended.sum()
+                extra = timeout & ~(doneb | finb)  # not yet reset by the fused step
+                if epoch_ended:
+                    extra = ~(doneb | finb)         # full reset (multi_ppo.py:244-264)
+                    terminal = torch.ones_like(terminal)
+                    ended = torch.ones_like(ended)
+                may_time_out = since_full_reset > self.max_ep_len
+                if epoch_ended or (may_time_out and bool(extra.any())):
+                    env.reset_drones(extra)
+                    env.observe(obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
+                buf.finish_path(terminal)
+                self.ep_ret = torch.where(ended, torch.zeros_like(self.ep_ret), self.ep_ret)
+                self.ep_len = torch.where(ended, torch.zeros_like(self.ep_len), self.ep_len)
+        self._cur = (buf.obs[self.steps_per_epoch], buf.cnt[self.steps_per_epoch])
         return float(ret_sum / ret_n.clamp(min=1))
 
     def training_loop(self):
