@@ -213,6 +213,22 @@ class BatchedDroneEnv:
                                               self._stream()), "rvo3d_set_state")
         self._keep = t
 
+    # -- checkpoint / resume -----------------------------------------------------------
+    def state_dict(self):
+        """The complete mutable state of every drone (drone.py:14-82) as CPU tensors, plus the
+        shape it belongs to: enough to resume a rollout bit-exactly (the values the step keeps
+        on file between calls are derived data and are rebuilt by load_state_dict)."""
+        sd = {k: v.cpu() for k, v in self.get_state().items()}
+        sd["shape"] = torch.tensor([self.E, self.N, self.P, self.nm])
+        return sd
+
+    def load_state_dict(self, sd):
+        shape = [int(x) for x in sd["shape"]]
+        if shape != [self.E, self.N, self.P, self.nm]:
+            raise ValueError(f"checkpoint is for E,N,P,nm = {shape}, this env has "
+                             f"{[self.E, self.N, self.P, self.nm]}")
+        self.set_state(**{k: v for k, v in sd.items() if k != "shape"})
+
     def error_flags(self) -> int:
         """Reads and clears the device error word (synchronises)."""
         f = C.c_uint32(0)

@@ -464,3 +464,30 @@ def test_full_size_launch_matches_oracle_on_sampled_envs(E, N, nb, size):
     assert env.error_flags() == (1 if ref.nan_count else 0)
     env.close()
     print(tl.finish())
+
+
+def test_env_checkpoint_resume_is_bit_exact(tmp_path):
+    """state_dict -> torch.save -> load (weights_only) -> load_state_dict resumes the rollout
+    exactly: every output of the following steps is identical."""
+    E, N = 32, 24
+    world = synthetic_world(E, N, (20.0, 20.0, 8.0), n_points=3, seed=3)
+    acts = [torch.from_numpy(synthetic_actions(E, N, t, 5).astype(np.float32)).cuda() for t in range(30)]
+    env = BatchedDroneEnv(world, neighbors_num=10, action_decimals=2)
+    env.observe()
+    for t in range(12):
+        env.step(acts[t], autoreset=True)
+    torch.save(env.state_dict(), tmp_path / "env.pt")
+    outs_a = []
+    for t in range(12, 30):
+        outs_a.append([x.clone() for x in env.step(acts[t], autoreset=True)] + [env.reset_mask.clone()])
+    final_a = {k: v.clone() for k, v in env.get_state().items()}
+    env.close()
+    env2 = BatchedDroneEnv(world, neighbors_num=10, action_decimals=2)
+    env2.load_state_dict(torch.load(tmp_path / "env.pt", weights_only=True))
+    for t in range(12, 30):
+        outs_b = list(env2.step(acts[t], autoreset=True)) + [env2.reset_mask]
+        for xa, xb in zip(outs_a[t - 12], outs_b):
+            assert torch.equal(torch.nan_to_num(xa.float(), nan=-7.0), torch.nan_to_num(xb.float(), nan=-7.0)), t
+    for k, v in env2.get_state().items():
+        assert torch.equal(v, final_a[k]), k
+    env2.close()
