@@ -105,11 +105,19 @@ __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int
       o[12 + 9 * s + k] = round2_f32(row[k]);
     }
   }
+  P.vo_count[g] = kept;
+  if (bad) atomicOr(P.err, 1u);
+}
+
+// The zero run behind the kept rows of one observation row: this lane writes the pieces that
+// the cooperative fill (zero_fill) cannot - the odd float with 8-B units, the 8-B pieces that
+// do not fill a 16-B chunk at either end - and publishes the run as a chunk range [c0, c1).
+__device__ __forceinline__ void publish_zero_run(const Params& P, const Lds& L, int tid, int g,
+                                                 int kept) {
+  float* o = P.obs + (size_t)g * P.W;
   // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
   if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
   if (P.zf16) {
-    // 16-B zero-fill: this lane writes the 8-B pieces that do not fill a 16-B chunk at
-    // either end of its zero run and publishes the run as a chunk range [c0, c1)
     const unsigned long long rb = 4ull * (unsigned)P.W;
     const unsigned long long row_b = rb * (unsigned long long)g;
     unsigned long long zs = row_b + 4ull * (unsigned)((12 + 9 * kept + 1) & ~1);
@@ -121,8 +129,6 @@ __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int
     L.zc[2 * tid] = (uint32_t)(zs >> 4);
     L.zc[2 * tid + 1] = (uint32_t)(ze >> 4);
   }
-  P.vo_count[g] = kept;
-  if (bad) atomicOr(P.err, 1u);
 }
 
 // Cooperative, coalesced zero padding of the VO region of every row of this
@@ -373,6 +379,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (active) {
       write_proprio(P, g, S, proprio_tail(dv, dev));
       write_vo_rows(P, L, tid, lbase, g, S, kept);
+      publish_zero_run(P, L, tid, g, kept);
       L.kept[tid] = kept;
       P.max_dev()[g] = max_dev;
       uint32_t dvk_a, dvk_b;
@@ -588,21 +595,27 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);
+  // kept rows first (their loads from the row scratch would otherwise queue behind the fill's
+  // stores), then the zero fill, whose stores drain while the proprioceptive part is
+  // converted and written behind it (disjoint bytes of the same rows)
   if (active) {
     if (!(P.ablate & 8)) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
-      write_proprio(P, g, S, ptail);
+      publish_zero_run(P, L, tid, g, kept);
     }
     L.kept[tid] = kept;
+  }
+  __syncthreads();  // L.kept / L.zc complete
+  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
+  RVO3D_STAMP(8);
+  if (active) {
+    if (!(P.ablate & 8)) write_proprio(P, g, S, ptail);
     P.max_dev()[g] = max_dev;
 #pragma unroll
     for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     P.px()[g] = S.x; P.py()[g] = S.y; P.pz()[g] = S.z;
     P.vx()[g] = S.vx; P.vy()[g] = S.vy; P.vz()[g] = S.vz;
   }
-  __syncthreads();  // L.kept complete
-  RVO3D_STAMP(8);
-  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
   RVO3D_STAMP(9);
 }
 

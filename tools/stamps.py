@@ -17,7 +17,7 @@ _lib.check(_lib.lib().rvo3d_debug_stamps(env._h, C.c_void_p(buf.data_ptr())), "s
 env.step(acts[10], autoreset=True)
 torch.cuda.synchronize()
 s = buf.cpu().numpy().astype(np.int64)
-names = ["load+dronestate", "stage", "sweepA", "integrate", "lite/sweepB", "reset", "final sweep", "store", "zero-fill"]
+names = ["load+dronestate", "stage", "sweepA", "integrate", "lite/sweepB", "reset", "final sweep", "rows + zero fill", "proprio + state stores"]
 d = np.diff(s[:, :10], axis=1)
 print("phase mean / p50 / p95 cycles (s_memtime ticks):")
 for i, n in enumerate(names):
