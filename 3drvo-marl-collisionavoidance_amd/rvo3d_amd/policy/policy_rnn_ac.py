@@ -247,11 +247,32 @@ class mlp_ac(nn.Module):
     def v(self, obs):
         return self.v_net(self._obs(obs)).squeeze(-1)
 
+    @staticmethod
+    def _fused_forward(net, x):
+        """Inference-only forward of an mlp() stack whose hidden activations are ReLU: bias +
+        ReLU run in the GEMM epilogue (hipBLASLt, `torch._addmm_activation`) instead of a
+        separate pass over the [E*N, 256] activations; bf16 operands under autocast."""
+        mods = list(net)
+        lin = [m for m in mods if isinstance(m, nn.Linear)]
+        acts = [m for m in mods if not isinstance(m, nn.Linear)]
+        if len(acts) != len(lin) or not all(isinstance(m, nn.ReLU) for m in acts[:-1]):
+            return net(x)
+        dt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
+        h = x.to(dt)
+        for m in lin[:-1]:
+            h = torch._addmm_activation(m.bias.to(dt), h, m.weight.to(dt).t(), use_gelu=False)
+        h = torch.nn.functional.linear(h, lin[-1].weight.to(dt), lin[-1].bias.to(dt))
+        return acts[-1](h)
+
     def step_tensors(self, obs, std_factor=1):
         with torch.no_grad():
-            d = self.dist(obs, std_factor)
+            x = self._obs(obs)
+            mu = self._fused_forward(self.pi_net, x).float()
+            std = torch.clamp(std_factor * torch.exp(self.log_std) + 1e-6, min=1e-4, max=10.0)
+            d = Normal(mu, std)
             a = d.sample()
-            return a, self.v(obs), d.log_prob(a).sum(-1)
+            v = self._fused_forward(self.v_net, x).float().squeeze(-1)
+            return a, v, d.log_prob(a).sum(-1)
 
     def step(self, obs, std_factor=1):
         a, v, lp = self.step_tensors(obs, std_factor)
