@@ -95,6 +95,16 @@ static inline void mgs_round(int site, double x, double f) { /* distance of x to
   double p = x * f;
   mgs(site, (fabs(p - floor(p) - 0.5)) / f);
 }
+/* Observation outputs are libm results (positions and velocities come out of sin / cos, the
+ * rows out of sqrt / asin / acos): a value EXACTLY on a rounding tie - e.g. vy = 0.3 * sin 18
+ * * cos 36 = 0.075 - falls to either side with the last ulp of the libm in use, so for them
+ * an exact tie is a knife edge too. */
+static inline void mgs_round0(int site, double x, double f) {
+  if (!isfinite(x)) return;
+  double p = x * f;
+  mgs0(site, (fabs(p - floor(p) - 0.5)) / f);
+}
+#define mg_round0(x, f) mgs_round0(__LINE__, (x), (f))
 #define mg(d) mgs(__LINE__, (d))
 #define mg0(d) mgs0(__LINE__, (d))
 #define mgx(d) mgs(__LINE__, (d))
@@ -516,10 +526,10 @@ static void write_obs(orc_env *h, const dstate *S, const double *rows, int count
   for (int k = 0; k < 12; ++k) {
     /* radius, priority and des_vel (already a 3-decimal value: its own rounding
      * is audited in cal_des_vel) are decimals, not libm results: a tie is robust */
-    if (k < 6 || k == 11) mg_round(S->s[k], 100.0);
+    if (k < 6 || k == 11) mg_round0(S->s[k], 100.0);
     obs[k] = np_round2(S->s[k]);
   }
-  for (int k = 0; k < 9 * count; ++k) { mg_round(rows[k], 100.0); obs[12 + k] = np_round2(rows[k]); }
+  for (int k = 0; k < 9 * count; ++k) { mg_round0(rows[k], 100.0); obs[12 + k] = np_round2(rows[k]); }
   for (int k = 12 + 9 * count; k < W; ++k) obs[k] = 0.0;
   for (int k = 0; k < W; ++k) if (!isfinite(obs[k])) bad = 1;
   if (bad) {
@@ -797,6 +807,7 @@ void orc_set_state(orc_env *h, const double *pos, const double *vel,
 }
 
 void orc_des_vel(const orc_env *h, double *des_vel) {
+  tl_margin = 0; tl_site = 0;  /* no audit here: never a stale pointer of an earlier env */
   for (int g = 0; g < h->E * h->N; ++g)
     cal_des_vel(h->p + 3 * (size_t)g, wp_at(h, g, h->wp_idx[g]), des_vel + 3 * (size_t)g);
 }
@@ -856,6 +867,7 @@ void orc_rvo_vel(const orc_env *h, const double *vmax, double acceler, double *o
   const int N = h->N;
 #pragma omp parallel for schedule(static) num_threads(h->threads)
   for (int g = 0; g < h->E * N; ++g) {
+    tl_margin = 0; tl_site = 0;  /* no audit here: never a stale pointer of an earlier env */
     const int e = g / N;
     const double *pa = h->p + 3 * (size_t)g, *va = h->v + 3 * (size_t)g;
     const double ra = h->radius[g], pra = h->prio[g];
