@@ -19,11 +19,16 @@ cases = [
     dict(E=8, N=200, size=(80, 80, 10), T=40, kw=dict(autoreset=True), nb=30),
     dict(E=16, N=128, size=(60, 60, 10), T=60, kw=dict(autoreset=True, vlike=True, nm=5)),
     dict(E=40, N=7, size=(10, 10, 6), T=150, kw=dict(autoreset=True, nm=10)),
+    # dense scenes: many flagged pairs, nm truncation, velocity-like actions
+    dict(E=64, N=32, size=(12, 12, 5), T=40, kw=dict(autoreset=False, vlike=True, nm=2, radius=0.3), min_sep=0.8),
+    dict(E=48, N=48, size=(14, 14, 5), T=40, kw=dict(autoreset=True, vlike=True, nm=10, radius=0.3), min_sep=0.8),
+    dict(E=32, N=64, size=(16, 16, 5), T=40, kw=dict(autoreset=False, vlike=True, nm=4, radius=0.25), min_sep=0.7),
 ]
+base = int(os.environ.get("SOAK_SEED", "0"))
 for i, c in enumerate(cases):
-    seeds = [1234, 99 + i]
+    seeds = [1234, 99 + i] if base == 0 else [base + 10 * i, base + 10 * i + 1]
     for sd in seeds:
-        w = synthetic_world(c["E"], c["N"], c["size"], nb=c.get("nb", 0), seed=sd)
+        w = synthetic_world(c["E"], c["N"], c["size"], nb=c.get("nb", 0), seed=sd, min_sep=c.get("min_sep", 1.0))
         t0 = time.time()
         st = T.run_vs_oracle(w, T=c["T"], seed=sd, **c["kw"])
         print(f"case {i} seed {sd}: {c['E']}x{c['N']} T={c['T']} {c['kw']} -> {st}  ({time.time()-t0:.1f}s)", flush=True)
