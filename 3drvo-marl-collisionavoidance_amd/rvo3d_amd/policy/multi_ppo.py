@@ -265,7 +265,7 @@ class multi_ppo:
                 loss_v.backward()
                 self._allreduce_grads()
                 self.vf_optimizer.step()
-        return dict(kl=kl, pi_steps=pi_steps, loss_v=float(loss_v))
+        return dict(kl=kl, pi_steps=pi_steps, loss_v=float(loss_v.detach()))
 
     def _obs_arg(self, data):
         return (data["obs"], data["cnt"]) if "cnt" in data else data["obs"]
