@@ -35,6 +35,8 @@ class BatchedDroneEnv:
             raise RuntimeError("rvo3d_amd needs a GPU: there is no CPU fallback "
                                "(the CPU oracle under oracle/ is test infrastructure only)")
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:  # "cuda" -> "cuda:<current>"
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.E, self.N, self.P = world.shape
         self.nm = int(neighbors_num)
         self.W = 12 + 9 * self.nm
