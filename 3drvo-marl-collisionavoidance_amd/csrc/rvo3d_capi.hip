@@ -103,6 +103,12 @@ int check(rvo3d_env* h, bool need_world) {
 
 template <int MODE, int NW>
 int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
+  if (NW == 1 && P.N == 64 && P.epb == 1) {  // the 64-drone instantiation (compile-time N)
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 64 : 0>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
+    HIP_TRY(hipGetLastError());
+    return RVO3D_OK;
+  }
   hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;

@@ -282,9 +282,13 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 #endif
 
 // The whole environment step, one launch.
-template <int MODE, int NW>
-__global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params P) {
+// NFIX = 64: the instantiation for exactly 64 drones per env (one env per wave): N and the
+// envs per workgroup are compile-time constants, so the index arithmetic of the sweeps folds.
+template <int MODE, int NW, int NFIX = 0>
+__global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params Pin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Params P = Pin;
+  if (NFIX) { P.N = NFIX; P.epb = 64 / NFIX; }
   const int tid = threadIdx.x, T = NW == 1 ? 64 : (int)blockDim.x, N = P.N;
   const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
   const int el = tid / N;
