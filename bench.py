@@ -170,7 +170,8 @@ def main():
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "kernel": "rvo3d::env_kernel<2, 1> (fused step + auto-reset)" if N <= 64 else
+                         "traffic": traffic, "kernel": ("rvo3d::env_kernel<2, 1, 64> (fused step + auto-reset)" if N == 64 else
+                                    "rvo3d::env_kernel<2, 1> (fused step + auto-reset)") if N <= 64 else
                                    "rvo3d::env_kernel<2, NW> (fused step + auto-reset)",
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
