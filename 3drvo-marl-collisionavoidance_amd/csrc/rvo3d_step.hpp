@@ -79,6 +79,83 @@ __device__ __forceinline__ void write_proprio(const Params& P, int g, const Dron
   if (bad) atomicOr(P.err, 1u);
 }
 
+// 16-B row writer, part 1: the lane's proprioceptive floats go to LDS (float2 [row][6], laid
+// over the fp32 image, which is dead by now) together with the start of the row's zero run in
+// 8-B units; row_fill16() then writes proprio and zeros of all rows with coalesced 16-B stores.
+__device__ __forceinline__ void stage_row(const Params& P, const Lds& L, int tid, int g,
+                                          const Drone& S, const ProprioTail& t, int kept) {
+  const double v[8] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio};
+  float f[12];
+  bool bad = t.bad;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    f[k] = round2_f32(v[k]);
+    bad |= !finite_d(v[k]);
+  }
+  f[8] = t.dv0; f[9] = t.dv1; f[10] = t.dv2; f[11] = t.dev;
+  float4* pro = reinterpret_cast<float4*>(L.w[0]) + 3 * tid;
+  pro[0] = make_float4(f[0], f[1], f[2], f[3]);
+  pro[1] = make_float4(f[4], f[5], f[6], f[7]);
+  pro[2] = make_float4(f[8], f[9], f[10], f[11]);
+  L.kept[tid] = ((12 + 9 * kept + 1) & ~1) >> 1;
+  // with 8-B units an odd 9*kept leaves one float between the kept rows and the zero run
+  if (((9 * kept) & 1) && kept < P.nm) P.obs[(size_t)g * P.W + 12 + 9 * kept] = 0.0f;
+  if (bad) atomicOr(P.err, 1u);
+}
+
+// 16-B row writer, part 2 (W even, obs 16-B aligned): the rows [row0, row0 + nrows) of this
+// workgroup are one contiguous byte range; every 16-B chunk of it is assembled from two 8-B
+// halves - proprio bytes from LDS, zeros inside a row's zero run, nothing inside the kept VO
+// rows (their lane wrote them) - and stored fully coalesced.  A half outside the range or
+// inside kept rows turns the store into an 8-B one.
+__device__ __forceinline__ void row_fill16(const Params& P, const Lds& L, int tid, int row0,
+                                           int nrows) {
+  const uint32_t q = (uint32_t)P.W >> 1;  // 8-B units per row
+  const unsigned long long ustart = (unsigned long long)q * (unsigned)row0;
+  const unsigned long long uend = (unsigned long long)q * (unsigned)(row0 + nrows);
+  const uint32_t cbeg = (uint32_t)(ustart >> 1), cend = (uint32_t)((uend + 1) >> 1);
+  const unsigned long long m40 = P.cold().zf_m40;
+  const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
+  float2* ob2 = reinterpret_cast<float2*>(P.obs);
+  float4* ob4 = reinterpret_cast<float4*>(P.obs);
+  for (uint32_t c = cbeg + tid; c < cend; c += 4 * L.T) {
+    uint32_t off0[4], off1[4];
+    int z0[4], z1[4];
+    float2 d0[4], d1[4];
+    bool in0[4], in1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t cu = c + u * L.T;
+      const uint32_t cc = cu < cend ? cu : c;
+      const unsigned long long u0 = 2ull * cc;
+      const uint32_t row = (uint32_t)((u0 * m40) >> 40);
+      uint32_t o0 = (uint32_t)(u0 - (unsigned long long)row * q), o1 = o0 + 1, row1 = row;
+      if (o1 == q) { o1 = 0; row1 = row + 1; }
+      in0[u] = (cu < cend) & (u0 >= ustart);
+      in1[u] = (cu < cend) & (u0 + 1 < uend);
+      int l0 = (int)row - row0, l1 = (int)row1 - row0;
+      l0 = l0 < 0 ? 0 : l0;
+      l1 = l1 > nrows - 1 ? nrows - 1 : l1;
+      z0[u] = L.kept[l0]; z1[u] = L.kept[l1];
+      d0[u] = pro2[l0 * 6 + (o0 < 5u ? o0 : 5u)];
+      d1[u] = pro2[l1 * 6 + (o1 < 5u ? o1 : 5u)];
+      off0[u] = o0; off1[u] = o1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t cu = c + u * L.T;
+      const bool p0 = off0[u] < 6u, p1 = off1[u] < 6u;
+      const bool v0 = in0[u] & (p0 | (off0[u] >= (uint32_t)z0[u]));
+      const bool v1 = in1[u] & (p1 | (off1[u] >= (uint32_t)z1[u]));
+      const float2 a = p0 ? d0[u] : make_float2(0.f, 0.f);
+      const float2 b = p1 ? d1[u] : make_float2(0.f, 0.f);
+      if (v0 & v1) ob4[cu] = make_float4(a.x, a.y, b.x, b.y);
+      else if (v0) ob2[2ull * cu] = a;
+      else if (v1) ob2[2ull * cu + 1] = b;
+    }
+  }
+}
+
 // The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
 // iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
 // behind them (written by zero_fill()).
@@ -381,10 +458,13 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision, gw, false);
     if (active) {
-      write_proprio(P, g, S, proprio_tail(dv, dev));
       write_vo_rows(P, L, tid, lbase, g, S, kept);
-      publish_zero_run(P, L, tid, g, kept);
-      L.kept[tid] = kept;
+      if (P.zf16) stage_row(P, L, tid, g, S, proprio_tail(dv, dev), kept);
+      else {
+        write_proprio(P, g, S, proprio_tail(dv, dev));
+        publish_zero_run(P, L, tid, g, kept);
+        L.kept[tid] = kept;
+      }
       P.max_dev()[g] = max_dev;
       uint32_t dvk_a, dvk_b;
       dv_encode(dv, dvk_a, dvk_b);
@@ -393,7 +473,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     }
     __syncthreads();
-    zero_fill(P, L, tid, e0 * N, nrows);
+    if (P.zf16) row_fill16(P, L, tid, e0 * N, nrows);
+    else zero_fill(P, L, tid, e0 * N, nrows);
     return;
   }
 
@@ -600,20 +681,24 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   RVO3D_STAMP(7);
   // kept rows first (their loads from the row scratch would otherwise queue behind the fill's
-  // stores), then the zero fill, whose stores drain while the proprioceptive part is
-  // converted and written behind it (disjoint bytes of the same rows)
+  // stores); then every other byte of the rows - proprio and zeros - in coalesced 16-B stores
+  // (a lane writing its own 48 proprio bytes costs as much as the whole zero fill: 64 rows =
+  // 64 partial cache lines per store instruction); the state stores drain behind them.
   if (active) {
     if (!(P.ablate & 8)) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
-      publish_zero_run(P, L, tid, g, kept);
+      if (P.zf16) stage_row(P, L, tid, g, S, ptail, kept);
+      else { write_proprio(P, g, S, ptail); publish_zero_run(P, L, tid, g, kept); }
     }
-    L.kept[tid] = kept;
+    if (!P.zf16) L.kept[tid] = kept;
   }
-  __syncthreads();  // L.kept / L.zc complete
-  if (!(P.ablate & 16)) zero_fill(P, L, tid, e0 * N, nrows);
+  __syncthreads();  // the staged rows / L.kept / L.zc complete
+  if (!(P.ablate & 16)) {
+    if (P.zf16) row_fill16(P, L, tid, e0 * N, nrows);
+    else zero_fill(P, L, tid, e0 * N, nrows);
+  }
   RVO3D_STAMP(8);
   if (active) {
-    if (!(P.ablate & 8)) write_proprio(P, g, S, ptail);
     P.max_dev()[g] = max_dev;
 #pragma unroll
     for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
