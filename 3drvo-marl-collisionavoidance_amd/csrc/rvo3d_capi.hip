@@ -245,6 +245,8 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   if ((P.W & 1) == 0) {
     C.zf_q = (uint32_t)(P.W / 2);  // row bytes / 8
     C.zf_m40 = ((1ull << 40) + C.zf_q - 1) / C.zf_q;
+    C.zf_dr = (uint32_t)(2 * threads) / C.zf_q;
+    C.zf_dq = (uint32_t)(2 * threads) % C.zf_q;
   }
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;

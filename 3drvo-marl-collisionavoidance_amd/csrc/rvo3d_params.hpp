@@ -33,6 +33,7 @@ struct Cold {
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
   uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
+  uint32_t zf_dr, zf_dq;  // (2 * threads) / zf_q and % zf_q: one lane's step from chunk to chunk
   int nb;
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)

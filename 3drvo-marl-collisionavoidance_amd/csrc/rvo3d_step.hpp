@@ -114,45 +114,59 @@ __device__ __forceinline__ void row_fill16(const Params& P, const Lds& L, int ti
   const unsigned long long ustart = (unsigned long long)q * (unsigned)row0;
   const unsigned long long uend = (unsigned long long)q * (unsigned)(row0 + nrows);
   const uint32_t cbeg = (uint32_t)(ustart >> 1), cend = (uint32_t)((uend + 1) >> 1);
-  const unsigned long long m40 = P.cold().zf_m40;
   const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
-  float2* ob2 = reinterpret_cast<float2*>(P.obs);
-  float4* ob4 = reinterpret_cast<float4*>(P.obs);
-  for (uint32_t c = cbeg + tid; c < cend; c += 4 * L.T) {
+  // (row, unit inside the row) of this lane's first chunk by one multiplication; the next
+  // chunk of the lane is T chunks = 2T units further: + dr rows, + dq units, one carry
+  const uint32_t dr = P.cold().zf_dr, dq = P.cold().zf_dq;
+  uint32_t c = cbeg + tid;
+  int lrow;
+  uint32_t o0;
+  {
+    const unsigned long long u0 = 2ull * c;
+    const uint32_t row = (uint32_t)((u0 * P.cold().zf_m40) >> 40);
+    o0 = (uint32_t)(u0 - (unsigned long long)row * q);
+    lrow = (int)row - row0;  // -1 for the half chunk in front of an odd start
+  }
+  const bool odd_start = (ustart & 1ull) != 0;
+  int pidx = lrow * 6;  // float2 index of the row's proprio in LDS (kept incrementally)
+  const int pstep = 6 * (int)dr;
+  char* ptr = reinterpret_cast<char*>(P.obs) + 16ull * c;
+  const size_t pinc = 16ull * (size_t)L.T;
+  // Row indices one outside [0, nrows) occur at the two ends of the range; the LDS words read
+  // for them are valid memory next to the arrays and never used (in0 / in1 are false there).
+  for (; c < cend; c += 4 * L.T) {
     uint32_t off0[4], off1[4];
     int z0[4], z1[4];
     float2 d0[4], d1[4];
-    bool in0[4], in1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t cu = c + u * L.T;
-      const uint32_t cc = cu < cend ? cu : c;
-      const unsigned long long u0 = 2ull * cc;
-      const uint32_t row = (uint32_t)((u0 * m40) >> 40);
-      uint32_t o0 = (uint32_t)(u0 - (unsigned long long)row * q), o1 = o0 + 1, row1 = row;
-      if (o1 == q) { o1 = 0; row1 = row + 1; }
-      in0[u] = (cu < cend) & (u0 >= ustart);
-      in1[u] = (cu < cend) & (u0 + 1 < uend);
-      int l0 = (int)row - row0, l1 = (int)row1 - row0;
-      l0 = l0 < 0 ? 0 : l0;
-      l1 = l1 > nrows - 1 ? nrows - 1 : l1;
-      z0[u] = L.kept[l0]; z1[u] = L.kept[l1];
-      d0[u] = pro2[l0 * 6 + (o0 < 5u ? o0 : 5u)];
-      d1[u] = pro2[l1 * 6 + (o1 < 5u ? o1 : 5u)];
+      const bool wrap = o0 + 1 == q;
+      const uint32_t o1 = wrap ? 0u : o0 + 1;
+      const int l1 = lrow + (wrap ? 1 : 0), pidx1 = pidx + (wrap ? 6 : 0);
+      z0[u] = L.kept[lrow]; z1[u] = L.kept[l1];
+      d0[u] = pro2[pidx + (int)(o0 < 5u ? o0 : 5u)];
+      d1[u] = pro2[pidx1 + (int)(o1 < 5u ? o1 : 5u)];
       off0[u] = o0; off1[u] = o1;
+      o0 += dq; lrow += (int)dr; pidx += pstep;
+      if (o0 >= q) { o0 -= q; lrow += 1; pidx += 6; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t cu = c + u * L.T;
+      const bool live = cu < cend;
+      const bool in0 = live & !(odd_start & (cu == cbeg));
+      const bool in1 = live & (2ull * cu + 1 < uend);
       const bool p0 = off0[u] < 6u, p1 = off1[u] < 6u;
-      const bool v0 = in0[u] & (p0 | (off0[u] >= (uint32_t)z0[u]));
-      const bool v1 = in1[u] & (p1 | (off1[u] >= (uint32_t)z1[u]));
+      const bool v0 = in0 & (p0 | (off0[u] >= (uint32_t)z0[u]));
+      const bool v1 = in1 & (p1 | (off1[u] >= (uint32_t)z1[u]));
       const float2 a = p0 ? d0[u] : make_float2(0.f, 0.f);
       const float2 b = p1 ? d1[u] : make_float2(0.f, 0.f);
-      if (v0 & v1) ob4[cu] = make_float4(a.x, a.y, b.x, b.y);
-      else if (v0) ob2[2ull * cu] = a;
-      else if (v1) ob2[2ull * cu + 1] = b;
+      char* const pc = ptr + (size_t)u * pinc;
+      if (v0 & v1) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
+      else if (v0) *reinterpret_cast<float2*>(pc) = a;
+      else if (v1) *reinterpret_cast<float2*>(pc + 8) = b;
     }
+    ptr += 4 * pinc;
   }
 }
 
