@@ -491,3 +491,29 @@ def test_env_checkpoint_resume_is_bit_exact(tmp_path):
     for k, v in env2.get_state().items():
         assert torch.equal(v, final_a[k]), k
     env2.close()
+
+
+def test_observation_buffer_alignment_paths_agree():
+    """The row writer has a 16-B path (W even, buffer 16-B aligned) and a generic one; a
+    caller-provided buffer that is only 8-B aligned must give the very same observations."""
+    E, N = 37, 24
+    world = synthetic_world(E, N, (14.0, 14.0, 6.0), seed=21, min_sep=0.6)
+    env = BatchedDroneEnv(world, neighbors_num=10, action_decimals=2)
+    flat = torch.full((E * N * env.W + 2,), 7.0, dtype=torch.float32, device="cuda")
+    view = flat[2:].view(E, N, env.W)          # 8 bytes off a 16-B boundary
+    assert view.data_ptr() % 16 == 8 and view.is_contiguous()
+    cnt2 = torch.zeros((E, N), dtype=torch.int32, device="cuda")
+    o1, c1 = env.observe()
+    o1, c1 = o1.clone(), c1.clone()
+    o2, c2 = env.observe(obs_out=view, cnt_out=cnt2)
+    assert torch.equal(o1, o2) and torch.equal(c1, c2)
+    for t in range(12):
+        a = torch.from_numpy(synthetic_actions(E, N, t, 3).astype(np.float32)).cuda()
+        st = env.state_dict()
+        oa = [x.clone() for x in env.step_policy(a, autoreset=True)]
+        env.load_state_dict(st)
+        ob = env.step_policy(a, autoreset=True, obs_out=view, cnt_out=cnt2)
+        for xa, xb in zip(oa, ob):
+            assert torch.equal(torch.nan_to_num(xa.float(), nan=-7.0), torch.nan_to_num(xb.float(), nan=-7.0)), t
+    assert float(flat[0]) == 7.0 and float(flat[1]) == 7.0  # nothing written in front of the view
+    env.close()
