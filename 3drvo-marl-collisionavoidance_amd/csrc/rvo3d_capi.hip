@@ -92,24 +92,42 @@ int carve(rvo3d_env* h) {
   return RVO3D_OK;
 }
 
-int check(rvo3d_env* h, bool need_world) {
+// Makes the handle's device current for the duration of one API call and puts the caller's
+// device back afterwards (a single-process multi-GPU program keeps its own current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  int enter(int dev) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != dev) {
+      e = hipSetDevice(dev);
+      changed = e == hipSuccess;
+    }
+    if (e != hipSuccess) return fail(RVO3D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return RVO3D_OK;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+int check(rvo3d_env* h, bool need_world, DeviceGuard& g) {
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   if (need_world && !h->world_loaded)
     return fail(RVO3D_ERR_STATE, "rvo3d_load_world has not been called");
-  hipError_t e = hipSetDevice(h->cfg.device);
-  if (e != hipSuccess) return fail(RVO3D_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-  return RVO3D_OK;
+  return g.enter(h->cfg.device);
 }
 
 template <int MODE, int NW>
 int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
-  if (NW == 1 && P.N == 64 && P.epb == 1) {  // the 64-drone instantiation (compile-time N)
+  if (!P.env_train) {  // the evaluator's env (train/policy_test.py:46): its own instantiations
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, 0, false>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+  } else if (NW == 1 && P.N == 64 && P.epb == 1) {  // the 64-drone instantiation (compile-time N)
     hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 64 : 0>), dim3(h->blocks), dim3(h->threads),
                        h->lds, s, P);
-    HIP_TRY(hipGetLastError());
-    return RVO3D_OK;
+  } else {
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
   }
-  hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
 }
@@ -126,7 +144,10 @@ int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
 
 template <int MODE, int NW>
 hipError_t allow_lds(int bytes) {
-  return hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW>,
+  hipError_t e = hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW, 0, false>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 template <int NW>
@@ -153,7 +174,8 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   if ((long long)cfg->num_envs * cfg->num_drones > (1ll << 30))
     return fail(RVO3D_ERR_INVALID, "num_envs * num_drones too large");
   if (cfg->action_decimals > 9) return fail(RVO3D_ERR_INVALID, "action_decimals must be <= 9");
-  HIP_TRY(hipSetDevice(cfg->device));
+  DeviceGuard dg;
+  if (int rc0 = dg.enter(cfg->device)) return rc0;
 
   rvo3d_env* h = new (std::nothrow) rvo3d_env();
   if (!h) return fail(RVO3D_ERR_INVALID, "out of host memory");
@@ -165,7 +187,9 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   P.E = cfg->num_envs; P.N = cfg->num_drones; P.P = cfg->max_points;
   C.nb = cfg->num_buildings; P.nm = cfg->neighbors_num; P.env_train = cfg->env_train ? 1 : 0;
   P.W = 12 + 9 * P.nm;
-  if (const char* ab = std::getenv("RVO3D_ABLATE")) P.ablate = std::atoi(ab);  // diagnostics only
+#ifdef RVO3D_DIAG
+  if (const char* ab = std::getenv("RVO3D_ABLATE")) P.ablate = std::atoi(ab);  // diagnostics build only
+#endif
   C.act_scale = cfg->action_decimals >= 0 ? std::pow(10.0, cfg->action_decimals) : 0.0;
   for (int k = 0; k < 3; ++k) C.map[k] = cfg->map_size[k];
   P.T10 = sq_threshold(10.0);  // rvo_inter.py:96
@@ -221,7 +245,9 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   if (epb > P.E) epb = P.E;
   const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)N, 64);
   size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, N, P.nw);
-  if (const char* pad = std::getenv("RVO3D_LDS_PAD")) lds += (size_t)std::atoi(pad);  // diagnostics: cap occupancy
+#ifdef RVO3D_DIAG
+  if (const char* pad = std::getenv("RVO3D_LDS_PAD")) lds += (size_t)std::atoi(pad);  // diagnostics build only: cap occupancy
+#endif
   if (lds > 160 * 1024) {
     delete h;
     return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");
@@ -272,7 +298,8 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
 
 int rvo3d_destroy(rvo3d_env* h) {
   if (!h) return RVO3D_OK;
-  (void)hipSetDevice(h->cfg.device);
+  DeviceGuard dg;
+  (void)dg.enter(h->cfg.device);
   (void)hipDeviceSynchronize();
   if (h->arena) (void)hipFree(h->arena);
   delete h;
@@ -282,7 +309,8 @@ int rvo3d_destroy(rvo3d_env* h) {
 int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_points,
                      const double* buildings, const double* radius, const double* priority,
                      void* stream) {
-  int rc = check(h, false);
+  DeviceGuard dg;
+  int rc = check(h, false, dg);
   if (rc) return rc;
   if (!waypoints || !n_points) return fail(RVO3D_ERR_INVALID, "waypoints / n_points are required");
   const Params& P = h->P;
@@ -364,7 +392,8 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
 }
 
 int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   const size_t EN = (size_t)h->P.E * h->P.N;
   h->g_valid = false;  // positions change: the stage-G words on file are stale
@@ -375,7 +404,8 @@ int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
 }
 
 int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   if (!drone_mask) return fail(RVO3D_ERR_INVALID, "drone_mask is required");
   const size_t EN = (size_t)h->P.E * h->P.N;
@@ -387,7 +417,8 @@ int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
 }
 
 int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   if (!obs || !vo_count) return fail(RVO3D_ERR_INVALID, "obs / vo_count are required");
   Params P = h->P;
@@ -401,7 +432,8 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
 static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
                        int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                        uint8_t* finish, uint8_t* reset_mask, bool autoreset, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   if (!actions || !obs || !vo_count || !reward || !done || !info || !finish)
     return fail(RVO3D_ERR_INVALID, "null I/O pointer");
@@ -454,7 +486,8 @@ int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype
 }
 
 int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   if (!des_vel) return fail(RVO3D_ERR_INVALID, "des_vel is required");
   const size_t EN = (size_t)h->P.E * h->P.N;
@@ -465,7 +498,8 @@ int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
 }
 
 int rvo3d_rvo_vel(rvo3d_env* h, const double* vmax, double acceler, double* out_vel, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   if (!vmax || !out_vel) return fail(RVO3D_ERR_INVALID, "vmax / out_vel are required");
   if (!(acceler >= 0.0 && acceler <= 1.0))
@@ -492,7 +526,8 @@ int rvo3d_state_ptrs(rvo3d_env* h, rvo3d_state_view* out) {
 int rvo3d_get_state(rvo3d_env* h, double* pos, double* vel, double* yaw, double* pitch,
                     double* real_len, double* max_dev, double* extra_len, int32_t* wp_idx,
                     uint8_t* arrive, uint8_t* dest, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   const Params& P = h->P;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -517,7 +552,8 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
                     const double* pitch, const double* real_len, const double* max_dev,
                     const double* extra_len, const int32_t* wp_idx, const uint8_t* arrive,
                     const uint8_t* dest, void* stream) {
-  int rc = check(h, true);
+  DeviceGuard dg;
+  int rc = check(h, true, dg);
   if (rc) return rc;
   h->dv_valid = h->g_valid = false;  // the next step recomputes the pre-move dronestate and stage G
   const Params& P = h->P;
@@ -543,7 +579,8 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
 }
 
 int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
-  int rc = check(h, false);
+  DeviceGuard dg;
+  int rc = check(h, false, dg);
   if (rc) return rc;
   if (!flags) return fail(RVO3D_ERR_INVALID, "flags is required");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -553,11 +590,15 @@ int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
   return RVO3D_OK;
 }
 
+#ifdef RVO3D_DIAG
+// diagnostics build only (librvo3d_hip_diag.so, tools/): attach a device buffer
+// [blocks][16] of s_memtime stamps, or NULL to detach
 int rvo3d_debug_stamps(rvo3d_env* h, unsigned long long* stamps) {
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   h->P.dbg = stamps;
   return RVO3D_OK;
 }
+#endif
 
 int rvo3d_launch_info(rvo3d_env* h, int32_t* threads, int32_t* envs_per_block, int32_t* blocks,
                       int32_t* lds_bytes) {

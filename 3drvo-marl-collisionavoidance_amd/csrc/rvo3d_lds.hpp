@@ -11,7 +11,6 @@ namespace rvo3d {
 struct Lds {
   double *x, *y, *z, *vx, *vy, *vz, *r, *prio;  // [T] fp64 image (exact stage)
   int* kept;                                     // [T] rows kept by the final sweep
-  uint32_t* zc;                                  // [2T] per row: first / end 16-B chunk of its zero run
   int* any_reset;                                // [epb]
   int* far;                                      // [epb] a drone is outside the fp32 filter's bound
   // fp32 image, each env's N slots stored twice ([el][2N]) so that neighbour
@@ -40,8 +39,7 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
   L.r = d + 6 * T; L.prio = d + 7 * T;
   L.mask2 = reinterpret_cast<unsigned long long*>(d + 8 * T);
   L.kept = reinterpret_cast<int*>(L.mask2 + (size_t)T * NW);
-  L.zc = reinterpret_cast<uint32_t*>(L.kept + T);
-  float* wf = reinterpret_cast<float*>(L.zc + 2 * T);
+  float* wf = reinterpret_cast<float*>(L.kept + T);
   const int FL = f32_len_nw(T, N, epb, NW), FS = f32_single_nw(N, epb, NW);
   // order: WX WY WZ WR doubled, then the single-copy arrays
   L.w[0] = wf; L.w[1] = wf + FL; L.w[2] = wf + 2 * FL; L.w[6] = wf + 3 * FL;
@@ -55,7 +53,7 @@ __device__ __forceinline__ Lds carve_lds(unsigned char* base, int T, int nm, int
 }
 __host__ __device__ inline size_t lds_bytes(int T, int nm, int epb, int N, int NW) {
   (void)nm;
-  return (size_t)T * 8 * 8 + (size_t)T * NW * 8 + (size_t)T * 12 +
+  return (size_t)T * 8 * 8 + (size_t)T * NW * 8 + (size_t)T * 4 +
          (size_t)f32_len_nw(T, N, epb, NW) * 16 + (size_t)f32_single_nw(N, epb, NW) * 32 +
          (size_t)epb * 8 + 16;
 }

@@ -18,6 +18,9 @@ __device__ __forceinline__ double pair_md(const Drone& S, const Drone& O) {
 // (rvo_inter.py:116-196) with get_alpha / get_PAA / vo_out_jud_vector / get_beta
 // (vel_obs3D.py:8-66, rvo_inter.py:212-228).  `a` is the action after the
 // "< 1e-5 -> 0" rule (rvo_inter.py:118).
+// TRAIN: rvo_inter.env_train as a compile-time constant (the env_train = False code - another
+// collision threshold and the "math domain error" report - stays out of the training kernels).
+template <bool TRAIN>
 __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, const Lds& L, int k,
                                              const double a[3]) {
   PairOut o;
@@ -31,7 +34,7 @@ __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, co
   const double ssum = sq(ry) + sq(rx) + sq(rz);  // dis ** 2 as rvo_inter.py:135 sums it
   const double R = S.r + Or;
   // dis <= thr without the sqrt unless ssum is within 1e-15 (relative) of thr^2
-  const double thr = P.env_train ? R : (S.r - kExpRadius + Or);
+  const double thr = TRAIN ? R : (S.r - kExpRadius + Or);
   const double thr2 = thr * thr;
   bool coll;
   if (ssum < thr2 * (1.0 - 1e-15)) coll = thr >= 0;
@@ -40,6 +43,19 @@ __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, co
   if (coll) { o.collision = true; return o; }
   const double dotp = S.vx * rx + S.vy * ry + S.vz * rz;
   if (dotp <= 0) return o;
+  if (!TRAIN && d2 < R * R * (1.0 + 1e-12)) {
+    // env_train = False, r - 0.2 + mr < dis < r + mr, approaching: get_alpha's
+    // asin((r + mr) / norm) raises ValueError("math domain error") in the reference
+    // (vel_obs3D.py:13) and aborts the step; here the pair is "no VO" and the event is
+    // reported through the error word (RVO3D_FLAG_DOMAIN_ERROR)
+    // (r + mr) / norm > 1  <=>  norm < r + mr (both correctly rounded): no division, and the
+    // square root only inside the 1e-15 band around (r + mr)^2
+    const double R2 = R * R;
+    if (d2 < R2 * (1.0 - 1e-15) || (d2 < R2 * (1.0 + 1e-15) && __builtin_sqrt(d2) < R)) {
+      atomicOr(P.err, 2u);
+      return o;
+    }
+  }
   const double Ovx = L.vx[k], Ovy = L.vy[k], Ovz = L.vz[k], Oprio = L.prio[k];
   // get_PAA (vel_obs3D.py:19-32); x / (x + x) == 0.5 exactly
   const double pr = (S.prio == Oprio) ? 0.5 : S.prio / (S.prio + Oprio);
@@ -204,7 +220,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
 //   stage X2 (fp64, requested pairs only): pair_eval.
 // G and X1 only ever drop pairs that pair_eval would return "nothing" for.
 // NW = ceil(N / 64): words per request mask (64 drones) and per offset mask (32 offsets).
-template <int NW, bool ROWS, bool TOUCH>
+template <int NW, bool ROWS, bool TOUCH, bool TRAIN>
 __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
                                          int g, bool active, const Drone& S, const double a[3],
                                          bool zero_act, bool& flag, double& tmin,
@@ -237,7 +253,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         cand = far ? valid[w] : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
         gw[w] = cand;
       }
-      if (P.ablate & 64) cand = 0;
+      if (RVO3D_ABLATED(64)) cand = 0;
       if (ROWS && !TOUCH) RVO3D_STAMP(11);
       // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd
       // count repeats its last candidate: the requests are idempotent ORs)
@@ -341,7 +357,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
   if (ROWS && !TOUCH) RVO3D_STAMP(12);
   if (!ROWS) RVO3D_STAMP(14);
   __syncthreads();
-  if (active && !(P.ablate & 32)) {
+  if (active && !RVO3D_ABLATED(32)) {
     const int lbase = el * N;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -349,7 +365,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
       while (m2) {  // stage X2: exact, requested pairs only
         const int j = 64 * w + __builtin_ctzll(m2);
         m2 &= m2 - 1;
-        const PairOut po = pair_eval(P, S, L, lbase + j, a);
+        const PairOut po = pair_eval<TRAIN>(P, S, L, lbase + j, a);
         if (TOUCH && po.collision) collision = true;
         if (po.flag) {
           flag = true;
@@ -369,7 +385,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 // position, with dis <= r + mr (env_train) - for every drone of the env.  Each
 // unordered pair is tested once; the fp32 stage only selects pairs that are possibly
 // touching, the decision itself is fp64.
-template <int NW>
+template <int NW, bool TRAIN>
 __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int lane, int el,
                                             int d, bool active, const Drone& S,
                                             uint32_t gw[NW]) {
@@ -407,11 +423,20 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
         const double Or = L.r[k];
         const double dis = __builtin_sqrt(sq(ry) + sq(rx) + sq(rz));
         bool ci, cj;
-        if (P.env_train) {
+        if (TRAIN) {
           ci = cj = dis <= S.r + Or;
         } else {  // rvo_inter.py:145-147: r - exp_radius + mr, evaluated from each side
           ci = dis <= S.r - kExpRadius + Or;
           cj = dis <= Or - kExpRadius + S.r;
+          // the shell r - 0.2 + mr < dis < r + mr: the reference raises "math domain error"
+          // for the side(s) that approach (see pair_eval); the rows sweep that follows only
+          // sees the envs that did not reset, so the event is reported here as well
+          const double R = S.r + Or;
+          if (d2 < R * R * (1.0 + 1e-12) && __builtin_sqrt(d2) < R) {
+            const bool ai = !ci && S.vx * rx + S.vy * ry + S.vz * rz > 0;
+            const bool aj = !cj && L.vx[k] * -rx + L.vy[k] * -ry + L.vz[k] * -rz > 0;
+            if (ai || aj) atomicOr(P.err, 2u);
+          }
         }
         if (ci) coll = true;
         if (cj) atomicOr(&L.mask2[k * NW], 1ull);

@@ -32,7 +32,7 @@ struct Cold {
   float kdot;         // fp32 error bound of v.rel per unit |v|_1
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
-  uint32_t zf_q;      // 16-B zero-fill (W even): row bytes / 8
+  uint32_t zf_q;      // 16-B row writer (W even): row bytes / 8
   uint32_t zf_dr, zf_dq;  // (2 * threads) / zf_q and % zf_q: one lane's step from chunk to chunk
   int nb;
   const double* bld;       // [nb][4]
@@ -54,7 +54,9 @@ struct Params {
   int g_cached;       // 1: gcache holds the in-range words (stage G) of the current state
   int action_mode;    // 0: absolute action; 1: policy increment (trainer glue, multi_ppo.py:196-205)
   float acceler;      // ir_gym.acceler as numpy sees it next to a float32 array (float32)
-  int ablate;         // diagnostics only (env RVO3D_ABLATE): bit k skips phase k, results invalid
+#ifdef RVO3D_DIAG
+  int ablate;         // diagnostics build only (tools/): bit k skips phase k, results invalid
+#endif
   int zf16;           // per call: obs is 16-B aligned and W is even -> 16-B zero-fill
   double T10;         // max{x : sqrt(x) <= 10}  (rvo_inter.py:96)
   // fp32 candidate filter (stage G): error bands
@@ -129,7 +131,9 @@ struct Params {
   uint32_t* err;
   const Cold* cold_;   // device copy of the rarely used parameters
   __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
-  unsigned long long* dbg;  // diagnostics: per-workgroup s_memtime stamps [blocks][16], or null
+#ifdef RVO3D_DIAG
+  unsigned long long* dbg;  // diagnostics build only: per-workgroup s_memtime stamps [blocks][16], or null
+#endif
   // per-call I/O
   const void* actions;
   float* obs;
@@ -138,11 +142,19 @@ struct Params {
   uint8_t *done, *info, *finish, *reset_mask;
 };
 
-// diagnostic aid: phase stamps of lane 0, only when a stamp buffer is attached
-// (rvo3d_debug_stamps; tools/stamps.py)
+// Diagnostics exist only in the -DRVO3D_DIAG build (librvo3d_hip_diag.so, made and loaded by
+// tools/ alone): phase stamps of lane 0 (rvo3d_debug_stamps; tools/stamps.py) and phase
+// ablation (RVO3D_ABLATE; tools/pmc_ablate.sh).  The product library contains neither: no
+// environment variable and no call can make its step skip work.
+#ifdef RVO3D_DIAG
 #define RVO3D_STAMP(i)                                                                  \
   do {                                                                                  \
     if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#define RVO3D_ABLATED(bits) ((P.ablate & (bits)) != 0)
+#else
+#define RVO3D_STAMP(i) do { } while (0)
+#define RVO3D_ABLATED(bits) false
+#endif
 
 }  // namespace rvo3d

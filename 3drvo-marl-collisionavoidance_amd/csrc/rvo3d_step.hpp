@@ -108,33 +108,36 @@ __device__ __forceinline__ void stage_row(const Params& P, const Lds& L, int tid
 // halves - proprio bytes from LDS, zeros inside a row's zero run, nothing inside the kept VO
 // rows (their lane wrote them) - and stored fully coalesced.  A half outside the range or
 // inside kept rows turns the store into an 8-B one.
+// All index arithmetic is RELATIVE to the workgroup's first 8-B unit (values below
+// 2 * T * q + q, whatever E * N is); only the base pointer is 64-bit.
 __device__ __forceinline__ void row_fill16(const Params& P, const Lds& L, int tid, int row0,
                                            int nrows) {
   const uint32_t q = (uint32_t)P.W >> 1;  // 8-B units per row
   const unsigned long long ustart = (unsigned long long)q * (unsigned)row0;
-  const unsigned long long uend = (unsigned long long)q * (unsigned)(row0 + nrows);
-  const uint32_t cbeg = (uint32_t)(ustart >> 1), cend = (uint32_t)((uend + 1) >> 1);
+  const uint32_t odd = (uint32_t)(ustart & 1ull);  // the range starts in the middle of a chunk
+  const uint32_t ulen = q * (uint32_t)nrows;       // units of this workgroup
+  const uint32_t nchunks = (ulen + odd + 1u) >> 1;
   const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
   // (row, unit inside the row) of this lane's first chunk by one multiplication; the next
   // chunk of the lane is T chunks = 2T units further: + dr rows, + dq units, one carry
   const uint32_t dr = P.cold().zf_dr, dq = P.cold().zf_dq;
-  uint32_t c = cbeg + tid;
-  int lrow;
-  uint32_t o0;
+  int lrow;      // row of the chunk's first half, relative to row0 (-1: the half chunk in
+  uint32_t o0;   // front of an odd start), and its unit inside that row
   {
-    const unsigned long long u0 = 2ull * c;
-    const uint32_t row = (uint32_t)((u0 * P.cold().zf_m40) >> 40);
-    o0 = (uint32_t)(u0 - (unsigned long long)row * q);
-    lrow = (int)row - row0;  // -1 for the half chunk in front of an odd start
+    const int v = 2 * tid - (int)odd;  // first unit of the lane's first chunk, relative
+    if (v < 0) { lrow = -1; o0 = q - 1; }
+    else {
+      lrow = (int)(((unsigned long long)(uint32_t)v * P.cold().zf_m40) >> 40);
+      o0 = (uint32_t)v - (uint32_t)lrow * q;
+    }
   }
-  const bool odd_start = (ustart & 1ull) != 0;
   int pidx = lrow * 6;  // float2 index of the row's proprio in LDS (kept incrementally)
   const int pstep = 6 * (int)dr;
-  char* ptr = reinterpret_cast<char*>(P.obs) + 16ull * c;
+  char* ptr = reinterpret_cast<char*>(P.obs) + 16ull * ((ustart >> 1) + (unsigned)tid);
   const size_t pinc = 16ull * (size_t)L.T;
   // Row indices one outside [0, nrows) occur at the two ends of the range; the LDS words read
   // for them are valid memory next to the arrays and never used (in0 / in1 are false there).
-  for (; c < cend; c += 4 * L.T) {
+  for (uint32_t c = (uint32_t)tid; c < nchunks; c += 4 * L.T) {
     uint32_t off0[4], off1[4];
     int z0[4], z1[4];
     float2 d0[4], d1[4];
@@ -153,9 +156,9 @@ __device__ __forceinline__ void row_fill16(const Params& P, const Lds& L, int ti
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const uint32_t cu = c + u * L.T;
-      const bool live = cu < cend;
-      const bool in0 = live & !(odd_start & (cu == cbeg));
-      const bool in1 = live & (2ull * cu + 1 < uend);
+      const bool live = cu < nchunks;
+      const bool in0 = live & !((odd != 0) & (cu == 0));
+      const bool in1 = live & (2u * cu + 1u - odd < ulen);
       const bool p0 = off0[u] < 6u, p1 = off1[u] < 6u;
       const bool v0 = in0 & (p0 | (off0[u] >= (uint32_t)z0[u]));
       const bool v1 = in1 & (p1 | (off1[u] >= (uint32_t)z1[u]));
@@ -200,62 +203,19 @@ __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int
   if (bad) atomicOr(P.err, 1u);
 }
 
-// The zero run behind the kept rows of one observation row: this lane writes the pieces that
-// the cooperative fill (zero_fill) cannot - the odd float with 8-B units, the 8-B pieces that
-// do not fill a 16-B chunk at either end - and publishes the run as a chunk range [c0, c1).
-__device__ __forceinline__ void publish_zero_run(const Params& P, const Lds& L, int tid, int g,
-                                                 int kept) {
-  float* o = P.obs + (size_t)g * P.W;
-  // with 8-B zero-fill units an odd 9*kept leaves one float for this lane
-  if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) o[12 + 9 * kept] = 0.0f;
-  if (P.zf16) {
-    const unsigned long long rb = 4ull * (unsigned)P.W;
-    const unsigned long long row_b = rb * (unsigned long long)g;
-    unsigned long long zs = row_b + 4ull * (unsigned)((12 + 9 * kept + 1) & ~1);
-    unsigned long long ze = row_b + rb;
-    char* ob = reinterpret_cast<char*>(P.obs);
-    if (zs < ze && (zs & 8)) { *reinterpret_cast<float2*>(ob + zs) = make_float2(0.f, 0.f); zs += 8; }
-    if (zs < ze && (ze & 8)) { ze -= 8; *reinterpret_cast<float2*>(ob + ze) = make_float2(0.f, 0.f); }
-    if (zs > ze) zs = ze;
-    L.zc[2 * tid] = (uint32_t)(zs >> 4);
-    L.zc[2 * tid + 1] = (uint32_t)(ze >> 4);
-  }
+// Generic row writer (W odd, or obs not 16-B aligned; the 16-B path is stage_row + row_fill16).
+// The zero run behind the kept rows of one observation row: with 8-B zero-fill units an odd
+// 9 * kept leaves one float for this lane.
+__device__ __forceinline__ void publish_zero_run(const Params& P, int g, int kept) {
+  if ((P.W & 1) == 0 && ((9 * kept) & 1) && kept < P.nm) P.obs[(size_t)g * P.W + 12 + 9 * kept] = 0.0f;
 }
 
 // Cooperative, coalesced zero padding of the VO region of every row of this
 // workgroup: rows [row0, row0 + nrows) are contiguous in memory; L.kept holds
 // the kept count per row.  Unit = float2 when W is even (rows 8-B aligned),
-// float otherwise.
+// float otherwise.  q < T * per_row (validated by rvo3d_create for the 32-bit magic).
 __device__ __forceinline__ void zero_fill(const Params& P, const Lds& L, int tid, int row0,
                                           int nrows) {
-  if (P.zf16) {
-    // rows [row0, row0 + nrows) occupy bytes [rb*row0, rb*(row0+nrows)); every 16-B chunk
-    // that starts inside a row's published zero run is stored, fully coalesced
-    const unsigned long long rb = 4ull * (unsigned)P.W;
-    const uint32_t cbeg = (uint32_t)((rb * (unsigned)row0 + 15) >> 4);
-    const uint32_t cend = (uint32_t)((rb * (unsigned)(row0 + nrows)) >> 4);
-    float4* ob = reinterpret_cast<float4*>(P.obs);
-    const uint2* zc2 = reinterpret_cast<const uint2*>(L.zc);
-    const unsigned long long m40 = P.cold().zf_m40;
-    // four chunks per trip: the run lookups (one 8-B LDS read each) are issued together
-    // and nothing in the body branches, so a trip costs one LDS round trip, not eight
-    for (uint32_t c = cbeg + tid; c < cend; c += 4 * L.T) {
-      uint2 z[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t cu = c + u * L.T;
-        const uint32_t cc = cu < cend ? cu : c;  // clamp: the lookup stays inside this block
-        const uint32_t grow = (uint32_t)(((unsigned long long)(2u * cc) * m40) >> 40);
-        z[u] = zc2[grow - (uint32_t)row0];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t cu = c + u * L.T;
-        if ((cu < cend) & (cu >= z[u].x) & (cu < z[u].y)) ob[cu] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    return;
-  }
   const uint32_t per_row = P.cold().zf_div;
   if (per_row == 0) return;
   const uint32_t total = (uint32_t)nrows * per_row;
@@ -375,7 +335,8 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 // The whole environment step, one launch.
 // NFIX = 64: the instantiation for exactly 64 drones per env (one env per wave): N and the
 // envs per workgroup are compile-time constants, so the index arithmetic of the sweeps folds.
-template <int MODE, int NW, int NFIX = 0>
+// TRAIN = rvo_inter.env_train (rvo_inter.py:14), a compile-time constant of the instantiation.
+template <int MODE, int NW, int NFIX = 0, bool TRAIN = true>
 __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params Pin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Params P = Pin;
@@ -469,14 +430,14 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       if (dev > max_dev) max_dev = dev;
     }
     uint32_t gw[NW];
-    const int kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active, S, zero3, true, flag,
+    const int kept = sweep_env<NW, true, true, TRAIN>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision, gw, false);
     if (active) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
       if (P.zf16) stage_row(P, L, tid, g, S, proprio_tail(dv, dev), kept);
       else {
         write_proprio(P, g, S, proprio_tail(dv, dev));
-        publish_zero_run(P, L, tid, g, kept);
+        publish_zero_run(P, g, kept);
         L.kept[tid] = kept;
       }
       P.max_dev()[g] = max_dev;
@@ -500,7 +461,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
 #pragma unroll
     for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
   }
-  sweep_env<NW, false, false>(P, L, tid, el, d, g, active && !(P.ablate & 1), S, az, false, flag,
+  sweep_env<NW, false, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(1), S, az, false, flag,
                               tmin, collision, gw, have_gw);
   // ---- everything else about this drone arrives in ONE batch of loads now (none of the
   //      addresses depends on a loaded value), then: drone.dronestate on the pre-move state
@@ -618,9 +579,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // state with the action, or on the post-reset state with action 0.
   int kept = 0;
   if (LITE) {
-    if (collide_env<NW>(P, L, tid, el, d, active && !(P.ablate & 2), S, gw)) collision = true;
+    if (collide_env<NW, TRAIN>(P, L, tid, el, d, active && !RVO3D_ABLATED(2), S, gw)) collision = true;
   } else {
-    kept = sweep_env<NW, true, true>(P, L, tid, el, d, g, active && !(P.ablate & 2), S, az, false,
+    kept = sweep_env<NW, true, true, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(2), S, az, false,
                                      flag, tmin, collision, gw, false);
   }
   bool do_reset = false;
@@ -689,8 +650,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       }
       have_gw2 = true;
     }
-    if (P.ablate & 2) have_gw2 = false;  // diagnostics: the collision sweep was skipped
-    kept = sweep_env<NW, true, false>(P, L, tid, el, d, g, active && !(P.ablate & 4), S, aa,
+    if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
+    kept = sweep_env<NW, true, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);
@@ -699,15 +660,15 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // (a lane writing its own 48 proprio bytes costs as much as the whole zero fill: 64 rows =
   // 64 partial cache lines per store instruction); the state stores drain behind them.
   if (active) {
-    if (!(P.ablate & 8)) {
+    if (!RVO3D_ABLATED(8)) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
       if (P.zf16) stage_row(P, L, tid, g, S, ptail, kept);
-      else { write_proprio(P, g, S, ptail); publish_zero_run(P, L, tid, g, kept); }
+      else { write_proprio(P, g, S, ptail); publish_zero_run(P, g, kept); }
     }
     if (!P.zf16) L.kept[tid] = kept;
   }
-  __syncthreads();  // the staged rows / L.kept / L.zc complete
-  if (!(P.ablate & 16)) {
+  __syncthreads();  // the staged rows / L.kept complete
+  if (!RVO3D_ABLATED(16)) {
     if (P.zf16) row_fill16(P, L, tid, e0 * N, nrows);
     else zero_fill(P, L, tid, e0 * N, nrows);
   }

@@ -33,18 +33,30 @@ def sources():
     return [os.path.join(_CSRC, "rvo3d_capi.hip")] + hpp + [os.path.join(_ROOT, "include", "rvo3d.h")]
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP extension for gfx950 (cross-compiles without a GPU)."""
+def build_hip(force: bool = False, verbose: bool = False, out: str | None = None,
+              extra_flags=()) -> str:
+    """Compile the HIP extension for gfx950 (cross-compiles without a GPU).  `out` /
+    `extra_flags` are for tools/diaglib.py (the -DRVO3D_DIAG build, kept outside the package)."""
     src = sources()
-    stale = (not os.path.exists(_SO)) or any(
-        os.path.getmtime(f) > os.path.getmtime(_SO) for f in src)
+    so = out or _SO
+    stale = (not os.path.exists(so)) or any(
+        os.path.getmtime(f) > os.path.getmtime(so) for f in src)
     if force or stale:
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", _SO, src[0]]
+        cmd = [hipcc] + HIPCC_FLAGS + list(extra_flags) + ["-o", so, src[0]]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return _SO
+    return so
+
+
+def use_library(path: str) -> None:
+    """tools/ only: load another build of the library (the diagnostics build) instead of the
+    product one.  Must be called before the first lib()."""
+    global _SO, _lib
+    if _lib is not None:
+        raise RuntimeError("the library is already loaded")
+    _SO = path
 
 
 class Config(C.Structure):
@@ -65,7 +77,7 @@ SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
            "rvo3d_step_policy",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
-           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_debug_stamps", "rvo3d_version", "rvo3d_last_error")
+           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_version", "rvo3d_last_error")
 
 _lib = None
 
@@ -97,7 +109,9 @@ def lib():
     L.rvo3d_set_state.argtypes = [vp] * 12
     L.rvo3d_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.rvo3d_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
-    L.rvo3d_debug_stamps.argtypes = [vp, vp]
+    if hasattr(L, "rvo3d_debug_stamps"):  # the diagnostics build (tools/diaglib.py) only
+        L.rvo3d_debug_stamps.argtypes = [vp, vp]
+        L.rvo3d_debug_stamps.restype = i32
     L.rvo3d_version.restype = i32
     L.rvo3d_last_error.restype = C.c_char_p
     for s in SYMBOLS:
@@ -105,6 +119,11 @@ def lib():
             getattr(L, s).restype = i32
     _lib = L
     return L
+
+
+def is_diag_build() -> bool:
+    """True when the loaded library is the -DRVO3D_DIAG build (never the case for the product)."""
+    return hasattr(lib(), "rvo3d_debug_stamps")
 
 
 def check(rc: int, what: str = ""):

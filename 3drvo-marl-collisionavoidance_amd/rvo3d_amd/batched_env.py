@@ -241,7 +241,10 @@ class BatchedDroneEnv:
     def check_finite(self):
         """The reference raises ValueError when an observation holds NaN/Inf
         (ir_gym.py:232-239); opt-in here because it synchronises."""
-        if self.error_flags() & 1:
+        f = self.error_flags()
+        if f & 2:  # RVO3D_FLAG_DOMAIN_ERROR: vel_obs3D.py:13 asin((r + mr) / norm), env_train=False
+            raise ValueError("math domain error")
+        if f & 1:
             raise ValueError("observation contains NaN/Inf")
 
     def launch_info(self):

@@ -74,9 +74,16 @@ class _IrGym:
         # k = 0 still yields one zero VO row (ir_gym.py:211-214)
         return [o[i, :12 + 9 * max(int(c[i]), 1)].copy() for i in range(len(c))]
 
+    def _raise_domain_error(self):
+        # env_train=False only: get_alpha raises out of the reference's step / observation when
+        # a pair inside r + mr approaches (vel_obs3D.py:13); the device reports it in its error word
+        if not self.env_train and (self._env.error_flags() & 2):
+            raise ValueError("math domain error")
+
     def env_observation(self):                      # ir_gym.py:372-383
         obs, cnt = self._env.observe()
         self._cache = None
+        self._raise_domain_error()
         return self._ragged(obs, cnt)
 
     def env_reset(self):                            # ir_gym.py:360-367
@@ -126,6 +133,7 @@ class mdin:
         obs, cnt, rew, done, info, fin = self._env.step(act)
         g = self.ir_gym
         g._cache = None
+        g._raise_domain_error()
         obs_list = g._ragged(obs, cnt)
         if not all(np.isfinite(o).all() for o in obs_list):
             raise ValueError("observation contains NaN/Inf")   # ir_gym.py:232-239

@@ -35,6 +35,7 @@ sys.path[:0] = [os.path.join(ROOT, "3drvo-marl-collisionavoidance_amd")]
 import numpy as np
 import torch
 
+ALLOW_DIAG = False  # set by tools/bench_diag.py only (the -DRVO3D_DIAG build of the library)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
@@ -92,7 +93,13 @@ def main():
     ap.add_argument("--no-autoreset", action="store_true")
     args = ap.parse_args()
 
-    from rvo3d_amd import BatchedDroneEnv, sharding, synthetic_actions, synthetic_world
+    from rvo3d_amd import BatchedDroneEnv, _lib, sharding, synthetic_actions, synthetic_world
+
+    # The product library has no diagnostics (no phase ablation, no stamps, reads no environment
+    # variable); a diagnostics build can only get here through tools/bench_diag.py.
+    diag = _lib.is_diag_build()
+    if diag and not ALLOW_DIAG:
+        raise SystemExit("bench.py refuses the diagnostics build of the library (use tools/bench_diag.py)")
 
     rank, local_rank, world = sharding.rank_info()
     if world != args.gpus and world > 1:
@@ -166,7 +173,8 @@ def main():
             "config": {"workload": f"BASELINE config 3 env.step: {N} drones x {E} envs per GPU, "
                                    f"nm={nm}, {nb} buildings, map {args.map}, fused step"
                                    f"{'+auto-reset' if autoreset else ''}, f32 actions in HBM",
-                       "envs_per_gpu": E, "drones": N, "launch": env.launch_info(),
+                       "envs_per_gpu": E, "drones": N, "launch": env.launch_info(), "diag_build": diag,
+                       "ablate": int(os.environ.get("RVO3D_ABLATE", "0")) if diag else 0,
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -41,8 +41,13 @@ enum { RVO3D_F32 = 0, RVO3D_F64 = 1 };
 
 /* bits of the device error word (rvo3d_error_flags) */
 enum {
-  RVO3D_FLAG_NONFINITE_OBS = 1 /* an observation held NaN/Inf: the reference
-                                  raises ValueError here (ir_gym.py:232-239) */
+  RVO3D_FLAG_NONFINITE_OBS = 1, /* an observation held NaN/Inf: the reference
+                                   raises ValueError here (ir_gym.py:232-239) */
+  RVO3D_FLAG_DOMAIN_ERROR = 2   /* env_train = 0 only: a pair with r - 0.2 + mr < dis < r + mr
+                                   was approaching; the reference's get_alpha raises
+                                   ValueError("math domain error") there (vel_obs3D.py:13,
+                                   rvo_inter.py:144-165) and aborts the step; here the pair
+                                   counts as "no velocity obstacle" and the step completes */
 };
 
 typedef struct rvo3d_env rvo3d_env;
@@ -174,10 +179,8 @@ int rvo3d_error_flags(rvo3d_env *h, uint32_t *flags, void *stream);
 int rvo3d_launch_info(rvo3d_env *h, int32_t *threads, int32_t *envs_per_block,
                       int32_t *blocks, int32_t *lds_bytes);
 
-/* Diagnostics: attach a device buffer of 16 uint64 per workgroup; lane 0 of every
- * workgroup then stores s_memtime stamps at the kernel's phase boundaries
- * (tools/stamps.py reads them).  NULL detaches.  Never attach it in a timed run. */
-int rvo3d_debug_stamps(rvo3d_env *h, unsigned long long *stamps);
+/* (Diagnostics - phase stamps, phase ablation - are not part of this library: they exist
+ * only in the -DRVO3D_DIAG build that tools/ makes for itself, include/rvo3d_diag.h.) */
 
 int rvo3d_version(void);
 const char *rvo3d_last_error(void);

@@ -26,6 +26,7 @@ Usage:  python oracle/gen_golden.py            (writes tests/golden/*.npz)
 """
 from __future__ import annotations
 
+import copy
 import json
 import math
 import os
@@ -70,6 +71,9 @@ def _install_standins():
 class _NoPlot:
     def __init__(self, *a, **k):
         pass
+
+    def __deepcopy__(self, memo):
+        return self
 
     def __getattr__(self, name):
         return lambda *a, **k: None
@@ -243,7 +247,16 @@ ACTORS["vslow"] = act_vslow
 
 
 def run_scenario(world, actor, T, seed, reset_on_finish=True, nm=NM, env_kw=None, scatter=None,
-                 radius=0.2):
+                 radius=0.2, state_fn=None, action_fn=None, observe_set=False, retry_on_raise=False):
+    """state_fn(env, rng, t) -> dict(pos, vel, yaw, pitch): custom per-step state overwrite
+    (instead of scatter_state); action_fn(env, rng, t): custom actions; observe_set: also
+    record ir_gym.env_observation() right after the overwrite (action 0, no other side
+    effect than dronestate's max_deviation, which the step repeats anyway).
+    A ValueError("math domain error") out of the step (get_alpha with env_train=False,
+    vel_obs3D.py:13) ends the scenario: the steps before it are kept and the inputs of the
+    raising step are recorded (raised = 1, raise_*).  retry_on_raise (scatter scenarios):
+    instead, the env is restored from a deep copy taken before the draw and a new state is
+    drawn (the number of rejected draws is recorded)."""
     rng = np.random.default_rng(seed)
     env = make_reference_env(world, nm=nm, **(env_kw or {}))
     N = env.ir_gym.drone_num
@@ -256,19 +269,64 @@ def run_scenario(world, actor, T, seed, reset_on_finish=True, nm=NM, env_kw=None
         wp[i, len(w):] = np.asarray(w[-1], dtype=np.float64)
     rec = dict(actions=[], obs=[], vo_count=[], reward=[], done=[], info=[], finish=[],
                reset_mask=[], obs_after=[], vo_count_after=[])
-    if scatter is not None:
+    if scatter is not None or state_fn is not None:
         rec.update(set_pos=[], set_vel=[], set_yaw=[], set_pitch=[])
+    if observe_set:
+        rec.update(obs_set=[], vo_count_set=[])
+    raised = None
+    rejected = 0
     st = {k: [] for k in ("pos", "vel", "yaw", "pitch", "real_len", "max_dev", "extra_len",
                           "wp_idx", "arrive", "dest")}
     obs0, cnt0 = pad_obs(env.drone_reset(False), nm)
     with np.errstate(all="ignore"):
         for t in range(T):
-            if scatter is not None:
-                ss = scatter_state(env, rng, scatter)
+            ss = oset = None
+            attempts = 0
+            while True:
+                snap = copy.deepcopy(env) if retry_on_raise else None
+                step_raise = None
+                ss = None
+                if state_fn is not None:
+                    ss = state_fn(env, rng, t)
+                    for i, d in enumerate(env.ir_gym.drone_list):
+                        d.state = np.array(ss["pos"][i], dtype=np.float64)
+                        d.vel = np.array(ss["vel"][i], dtype=np.float64)
+                        d.yaw, d.pitch = float(ss["yaw"][i]), float(ss["pitch"][i])
+                elif scatter is not None:
+                    ss = scatter_state(env, rng, scatter)
+                oset = None
+                acts = None
+                try:
+                    if observe_set:
+                        step_raise = "observe"
+                        oset = pad_obs(env.ir_gym.env_observation(), nm)
+                    acts = action_fn(env, rng, t) if action_fn is not None else ACTORS[actor](env, rng)
+                    step_raise = "step"
+                    o, r, dn, inf, fin = env.drone_step(acts)
+                    step_raise = None
+                except ValueError as ex:
+                    if "math domain error" not in str(ex):
+                        raise
+                if step_raise is None:
+                    break
+                attempts += 1
+                if retry_on_raise and attempts < 200:
+                    env = snap  # the reference aborted mid-step: back to the state before it
+                    rejected += 1
+                    continue
+                raised = dict(where=np.array(step_raise))
+                if acts is not None:
+                    raised["actions"] = np.asarray(acts, dtype=np.float64)
+                if ss is not None:
+                    raised.update({"set_" + k: v for k, v in ss.items()})
+                break
+            if raised is not None:
+                break
+            if ss is not None:
                 for k, v in ss.items():
                     rec["set_" + k].append(v)
-            acts = ACTORS[actor](env, rng)
-            o, r, dn, inf, fin = env.drone_step(acts)
+            if oset is not None:
+                rec["obs_set"].append(oset[0]); rec["vo_count_set"].append(oset[1])
             po, pc = pad_obs(o, nm)
             rec["actions"].append(np.asarray(acts, dtype=np.float64))
             rec["obs"].append(po); rec["vo_count"].append(pc)
@@ -284,18 +342,37 @@ def run_scenario(world, actor, T, seed, reset_on_finish=True, nm=NM, env_kw=None
             for i in np.nonzero(mask)[0]:
                 env.drone_reset_one(False, int(i))
             if mask.any():
-                oa, ca = pad_obs(env.ir_gym.env_observation(), nm)
+                try:
+                    oa, ca = pad_obs(env.ir_gym.env_observation(), nm)
+                except ValueError as ex:
+                    if "math domain error" not in str(ex):
+                        raise
+                    # the re-observation after the resets raised: the step itself stays (it is
+                    # the last one; its resets are dropped from the record, nothing follows)
+                    raised = dict(where=np.array("observe_after"))
+                    mask[:] = False
+                    oa, ca = po, pc
             else:
                 oa, ca = po, pc
             rec["reset_mask"].append(mask.astype(np.uint8))
             rec["obs_after"].append(oa); rec["vo_count_after"].append(ca)
+            if raised is not None:
+                break
+    if not rec["actions"]:
+        return None  # raised on the very first step: nothing to keep
     out = {k: np.stack(v) for k, v in rec.items()}
     out.update({"state_" + k: np.stack(v) for k, v in st.items()})
+    if retry_on_raise:
+        out["rejected_raises"] = np.int32(rejected)  # state draws on which the reference raised
+    if raised is not None:
+        out["raised"] = np.uint8(1)
+        out.update({"raise_" + k: v for k, v in raised.items()})
     out.update(waypoints=wp, n_points=np.asarray(world["n_points_list"], np.int32),
                buildings=np.asarray(world["building_list"], dtype=np.float64).reshape(-1, 4),
                map_size=np.asarray(world["map_size"], dtype=np.float64),
                obs0=obs0, vo_count0=cnt0, nm=np.int32(nm), actor=np.array(actor),
-               seed=np.int64(seed), env_train=np.uint8(1), radius=np.float64(radius))
+               seed=np.int64(seed), env_train=np.uint8(bool((env_kw or {}).get("env_train", True))),
+               radius=np.float64(radius))
     return out
 
 
@@ -347,6 +424,10 @@ def _replay(fx, orc):
         if "set_pos" in fx:
             env.set_state(pos=fx["set_pos"][t][None], vel=fx["set_vel"][t][None],
                           yaw=fx["set_yaw"][t][None], pitch=fx["set_pitch"][t][None])
+        if "obs_set" in fx:
+            os_, cs_ = env.observe()
+            if not (_eq(os_[0], fx["obs_set"][t]) and np.array_equal(cs_[0], fx["vo_count_set"][t])):
+                bad.append(f"t={t} obs_set")
         obs, cnt, rew, done, info, fin = env.step(fx["actions"][t][None])
         for name, got in (("obs", obs), ("reward", rew)):
             if not _eq(got[0], fx[name][t]):
@@ -385,8 +466,14 @@ def oracle_margins(fx):
         if "set_pos" in fx:
             env.set_state(pos=fx["set_pos"][t][None], vel=fx["set_vel"][t][None],
                           yaw=fx["set_yaw"][t][None], pitch=fx["set_pitch"][t][None])
+        ms = None
+        if "obs_set" in fx:
+            env.observe()
+            ms = env.margin()[0]
         env.step(fx["actions"][t][None])
         m = env.margin()[0]
+        if ms is not None:
+            m = np.minimum(m, ms)
         if fx["reset_mask"][t].any():
             env.reset_drones(fx["reset_mask"][t][None])
             env.observe()

@@ -54,6 +54,9 @@ def lib():
         L.orc_get_margin.argtypes = [vp, dp, ip]
         L.orc_nan_count.restype = C.c_int64
         L.orc_nan_count.argtypes = [vp]
+        L.orc_domain_count.restype = C.c_int64
+        L.orc_domain_count.argtypes = [vp]
+        L.orc_vo_circle2.argtypes = [C.c_int, dp, dp, dp, dp, ip, dp, ip, dp, ip]
         L.orc_set_threads.argtypes = [vp, C.c_int]
         L.orc_py_round2.restype = C.c_double
         L.orc_py_round2.argtypes = [C.c_double]
@@ -212,5 +215,24 @@ class OracleEnv:
     def nan_count(self):
         return int(lib().orc_nan_count(self._h))
 
+    @property
+    def domain_count(self):
+        """Pairs on which the reference raises "math domain error" (env_train=False shell)."""
+        return int(lib().orc_domain_count(self._h))
+
     def set_threads(self, n):
         lib().orc_set_threads(self._h, int(n))
+
+
+def vo_circle2(env_train, self8, other8, action):
+    """rvo_inter.config_vo_circle2 for one pair: (obs9, flag, exp_time, collision, min_dis,
+    domain_error) - the reference's five return values plus "the reference raises here"."""
+    s8 = np.ascontiguousarray(self8, dtype=np.float64)[:8].copy()
+    o8 = np.ascontiguousarray(other8, dtype=np.float64)[:8].copy()
+    a = np.ascontiguousarray(action, dtype=np.float64)
+    obs = np.zeros(9)
+    flag, col, dom = (np.zeros(1, np.int32) for _ in range(3))
+    t, md = np.zeros(1), np.zeros(1)
+    lib().orc_vo_circle2(int(bool(env_train)), _dp(s8), _dp(o8), _dp(a), _dp(obs), _ip(flag),
+                         _dp(t), _ip(col), _dp(md), _ip(dom))
+    return obs, bool(flag[0]), float(t[0]), bool(col[0]), float(md[0]), bool(dom[0])

@@ -52,6 +52,7 @@ struct orc_env {
   int32_t *wp_idx;
   uint8_t *arrive, *dest;
   int64_t nan_count;
+  int64_t domain_count; /* pairs on which the reference raises "math domain error" (get_alpha) */
   double *margin;     /* [E*N] min decision margin of the last call (audit) */
   int32_t *msite;     /* [E*N] source line of the decision that set it */
   uint8_t *vnoise;    /* [E*N] velocity came out of a cancelled speed (pure libm noise) */
@@ -266,7 +267,7 @@ static void move_forward(orc_env *h, int g, const double *act) {
 /* ---- vel_obs ---------------------------------------------------------- */
 typedef struct {
   double obs[9]; /* PAA(3) rel(3) alpha min_dis iet */
-  int flag, collision;
+  int flag, collision, domain;
   double t, min_dis;
 } vo_inf;
 
@@ -309,22 +310,39 @@ static void config_vo_circle2(const orc_env *h, const dstate *S, const dstate *O
   mg(dis - (r + mr));
   if (h->env_train) {
     if (dis <= r + mr) { dis = r + mr; collision = 1; }
-  } else {
+  } else {                                                 /* rvo_inter.py:144-150 */
+    mg(dis - (r - EXP_RADIUS + mr));
     if (dis <= r - EXP_RADIUS + mr) collision = 1;
     if (dis <= r + mr) dis = r + mr;
   }
   out->flag = 0;
   out->collision = collision;
+  out->domain = 0;
   out->t = 0.0;
   out->min_dis = dis;
+  out->obs[0] = x; out->obs[1] = y; out->obs[2] = z;
+  out->obs[3] = rel[0]; out->obs[4] = rel[1]; out->obs[5] = rel[2];
+  out->obs[6] = out->obs[7] = out->obs[8] = 0.0;
   if (collision) return;                                   /* rvo_inter.py:152 */
   double dotp = vx * rel[0] + vy * rel[1] + vz * rel[2];
   mg(dotp); /* v == 0 exactly (reset / clamped speed) gives dotp == 0: robust */
+  out->obs[7] = out->obs[8] = -1.0;
   if (dotp <= 0) return;                                   /* rvo_inter.py:159 */
 
   /* get_alpha */
   double ab[3] = {mx - x, my - y, mz - z};
-  double alpha_raw = asin((r + mr) / norm3_blas(ab));
+  const double q = (r + mr) / norm3_blas(ab);
+  mg(q - 1.0);
+  if (q > 1.0) {
+    /* math.asin raises ValueError("math domain error") (vel_obs3D.py:13): reachable only
+     * with env_train = False, r - 0.2 + mr < dis < r + mr, approaching.  The reference
+     * aborts the whole step; here the pair counts as "no VO" and the event is counted
+     * (orc_domain_count) - the device sets RVO3D_FLAG_DOMAIN_ERROR at the same pairs. */
+    __atomic_add_fetch(&((orc_env *)h)->domain_count, 1, __ATOMIC_RELAXED);
+    out->domain = 1;
+    return;
+  }
+  double alpha_raw = asin(q);
   mg_round(alpha_raw, 100.0);
   double alpha = orc_py_round2(alpha_raw);
   /* get_PAA */
@@ -947,5 +965,26 @@ void orc_vo_inf(orc_env *h, int e, int i, const double *action, double *rows,
   work_free(w);
 }
 
+/* Call-level check of rvo_inter.config_vo_circle2 (rvo_inter.py:116-196): one pair, the
+ * 8-value records of self / other, either env_train mode. */
+void orc_vo_circle2(int env_train, const double *self8, const double *other8,
+                    const double *action, double *obs9, int32_t *vo_flag, double *exp_time,
+                    int32_t *collision, double *min_dis, int32_t *domain_error) {
+  orc_env h;
+  memset(&h, 0, sizeof h);
+  h.env_train = env_train;
+  dstate S, O;
+  memset(&S, 0, sizeof S); memset(&O, 0, sizeof O);
+  memcpy(S.s, self8, 8 * sizeof(double));
+  memcpy(O.s, other8, 8 * sizeof(double));
+  tl_margin = 0; tl_site = 0;
+  vo_inf v;
+  config_vo_circle2(&h, &S, &O, action, &v);
+  memcpy(obs9, v.obs, sizeof v.obs);
+  *vo_flag = v.flag; *exp_time = v.t; *collision = v.collision; *min_dis = v.min_dis;
+  *domain_error = v.domain;
+}
+
 int64_t orc_nan_count(const orc_env *h) { return h->nan_count; }
+int64_t orc_domain_count(const orc_env *h) { return h->domain_count; }
 void orc_set_threads(orc_env *h, int n) { h->threads = n < 1 ? 1 : n; }

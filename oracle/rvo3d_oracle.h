@@ -97,6 +97,18 @@ void orc_get_margin(const orc_env *h, double *out, int32_t *site /* source line,
  * reference raises ValueError, ir_gym.py:232-239). */
 int64_t orc_nan_count(const orc_env *h);
 
+/* Number of pairs, since creation, on which the reference raises ValueError("math domain
+ * error") out of get_alpha (vel_obs3D.py:13; env_train = False, r - 0.2 + mr < dis < r + mr,
+ * approaching): the reference aborts the step there, the oracle treats the pair as "no VO". */
+int64_t orc_domain_count(const orc_env *h);
+
+/* Call-level check of rvo_inter.config_vo_circle2 (rvo_inter.py:116-196) for one pair:
+ * self8 / other8 = [x y z vx vy vz radius priority].  obs9 is the reference's first list
+ * (early returns included), exp_time its third element, min_dis its fifth. */
+void orc_vo_circle2(int env_train, const double *self8, const double *other8,
+                    const double *action, double *obs9, int32_t *vo_flag, double *exp_time,
+                    int32_t *collision, double *min_dis, int32_t *domain_error);
+
 /* Worker threads for the env loop (OpenMP); 1 = scalar port. */
 void orc_set_threads(orc_env *h, int n);
 

@@ -25,6 +25,18 @@ def test_header_symbols_all_exported(so):
         assert hasattr(L, s), f"{s} not exported"
 
 
+def test_product_library_has_no_diagnostics(so):
+    """Phase ablation / LDS padding / phase stamps exist only in the -DRVO3D_DIAG build that
+    tools/diaglib.py makes for itself: the product library exports no rvo3d_debug_stamps and
+    does not even contain the names of the diagnostic environment variables."""
+    L = C.CDLL(so)
+    assert not hasattr(L, "rvo3d_debug_stamps")
+    blob = open(so, "rb").read()
+    for name in (b"RVO3D_ABLATE", b"RVO3D_LDS_PAD"):
+        assert name not in blob
+    assert b"getenv" not in blob
+
+
 def test_version_and_error_string(so):
     L = _lib.lib()
     assert L.rvo3d_version() == 1

@@ -3,7 +3,8 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "3drvo-marl-collisionavoidance_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import diaglib  # noqa: F401  the -DRVO3D_DIAG build: the product library has no stamps
 from rvo3d_amd import BatchedDroneEnv, synthetic_actions, synthetic_world, _lib
 E, N = int(os.environ.get("STAMPS_E", 4096)), 64
 env = BatchedDroneEnv(synthetic_world(E, N, (50, 50, 10)), action_decimals=2)
