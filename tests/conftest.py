@@ -15,3 +15,13 @@ for p in (ROOT, PKG_DIR, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X; runs the HIP path through the C-ABI")
+
+
+def pytest_sessionstart(session):
+    # the GPU parity tests append their knife-edge tallies to this file; start each session clean
+    f = os.path.join(ROOT, "gpurun_out", "parity_tally.json")
+    if os.path.exists(f):
+        try:
+            os.remove(f)
+        except OSError:
+            pass

@@ -8,7 +8,11 @@ Knife edges: a (drone, step) sample whose smallest decision margin in the
 oracle is below 1e-9 (orc_get_margin; e.g. speed = |v| + acc cancelling to
 +-1e-17, so the sign of v.rel is libm rounding noise in the reference itself)
 is exempt from the comparison.  The accounting (class Tally):
-  * exempt samples are counted and bounded: <= 1 % of the compared samples (+2);
+  * exempt samples are counted and bounded: <= 1 % of the compared samples, plus three
+    standard deviations of a 1 % binomial for the small runs (the share is inherent to the
+    inputs: with 2-decimal accelerations `speed + acc` cancels exactly with probability
+    ~1/200 per drone-step, observed 0.4-0.6 %); the LAST test of this file bounds the share
+    over all tests together at 1 % flat;
   * exempt samples that REALLY differed are counted per sample (knife_mismatch <= knife);
   * an env in which an exempt sample differed has a different future from then on: it
     leaves the comparison for the rest of the run (`dropped_envs`), it is not carried
@@ -92,7 +96,8 @@ class Tally:
         rec = dict(samples=self.samples, knife=self.knife, knife_mismatch=self.knife_mismatch,
                    dropped_envs=int(self.dropped.sum()), envs=len(self.dropped), **extra)
         _record_tally(self.name, rec)
-        assert self.knife <= KNIFE_SHARE * self.samples + 2, rec
+        lim = KNIFE_SHARE * self.samples
+        assert self.knife <= lim + 3.0 * np.sqrt(lim) + 2, rec
         assert self.knife_mismatch <= self.knife, rec
         return rec
 
@@ -636,3 +641,23 @@ def test_observation_buffer_alignment_paths_agree():
             assert torch.equal(torch.nan_to_num(xa.float(), nan=-7.0), torch.nan_to_num(xb.float(), nan=-7.0)), t
     assert float(flat[0]) == 7.0 and float(flat[1]) == 7.0  # nothing written in front of the view
     env.close()
+
+
+def test_zz_knife_edge_share_over_all_tests():
+    """Runs last: over every tally this session recorded, exempt samples stay below 1 % of the
+    compared samples and the exempt samples that really differed below 0.1 %."""
+    if not os.path.exists(_TALLY_FILE):
+        pytest.skip("no tally file (tests ran in another order)")
+    with open(_TALLY_FILE) as f:
+        allr = json.load(f)
+    allr.pop("TOTAL", None)
+    n = sum(r["samples"] for r in allr.values())
+    k = sum(r["knife"] for r in allr.values())
+    km = sum(r["knife_mismatch"] for r in allr.values())
+    dropped = sum(r["dropped_envs"] for r in allr.values())
+    tot = dict(tests=len(allr), samples=n, knife=k, knife_mismatch=km, dropped_envs=dropped,
+               knife_share=k / max(n, 1), mismatch_share=km / max(n, 1))
+    _record_tally("TOTAL", tot)
+    print(tot)
+    assert n > 1_000_000 or len(allr) < 50  # the full suite compares > 1e6 drone-steps
+    assert k <= KNIFE_SHARE * n and km <= 0.001 * n, tot
