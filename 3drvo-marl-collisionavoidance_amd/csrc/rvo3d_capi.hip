@@ -122,8 +122,20 @@ template <int MODE, int NW>
 int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
   if (!P.env_train) {  // the evaluator's env (train/policy_test.py:46): its own instantiations
     hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, 0, false>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
-  } else if (NW == 1 && P.N == 64 && P.epb == 1) {  // the 64-drone instantiation (compile-time N)
+  } else if (NW == 1 && P.N == 64 && P.epb == 1) {  // compile-time N (see env_kernel)
     hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 64 : 0>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
+  } else if (NW == 1 && P.N == 32 && P.epb == 2) {
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 32 : 0>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
+  } else if (NW == 1 && P.N == 16 && P.epb == 4) {
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 16 : 0>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
+  } else if (NW == 2 && P.N == 128) {
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 2 ? 128 : 0>), dim3(h->blocks), dim3(h->threads),
+                       h->lds, s, P);
+  } else if (NW == 4 && P.N == 256) {
+    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 4 ? 256 : 0>), dim3(h->blocks), dim3(h->threads),
                        h->lds, s, P);
   } else {
     hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
@@ -267,13 +279,7 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     }
     C.zf_magic = m;
   }
-  C.zf_q = 0; C.zf_m40 = 0;
-  if ((P.W & 1) == 0) {
-    C.zf_q = (uint32_t)(P.W / 2);  // row bytes / 8
-    C.zf_m40 = ((1ull << 40) + C.zf_q - 1) / C.zf_q;
-    C.zf_dr = (uint32_t)(2 * threads) / C.zf_q;
-    C.zf_dq = (uint32_t)(2 * threads) % C.zf_q;
-  }
+  C.zf_q = (P.W & 1) == 0 ? (uint32_t)(P.W / 2) : 0u;  // row bytes / 8: the 16-B row writer applies
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;

@@ -20,12 +20,15 @@ struct Lds {
   int T;
 };
 
-// floats per fp32 array: two copies of every env of the workgroup
-__host__ __device__ inline int f32_len(int T, int N, int epb) { return (2 * epb * N + 3) & ~3; }
-// One-wave workgroups (NW == 1: T = 64, epb * N <= 64) use fixed array lengths, so every LDS
-// array sits at a compile-time offset from one base (address = base + constant + 4 * index).
+// Floats per "doubled" fp32 array (x y z r).  A drone d reaches neighbour d + k, k <= N/2, at
+// slot d + k: one env per workgroup (NW > 1) stores its N slots followed by a second copy of
+// the first N/2 + 1 only (1.5 N instead of 2 N: at N = 256 that is what lets four workgroups
+// share a CU's 160 KiB).  One-wave workgroups (NW == 1: T = 64, epb * N <= 64) keep two full
+// copies per env at a fixed array length, so every LDS array sits at a compile-time offset
+// from one base (address = base + constant + 4 * index).
 __host__ __device__ inline int f32_len_nw(int T, int N, int epb, int NW) {
-  return NW == 1 ? 128 : f32_len(T, N, epb);
+  (void)T; (void)epb;
+  return NW == 1 ? 128 : ((N + (N >> 1) + 1 + 3) & ~3);
 }
 __host__ __device__ inline int f32_single_nw(int N, int epb, int NW) {
   return NW == 1 ? 64 : ((epb * N + 3) & ~3);

@@ -138,7 +138,9 @@ __device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, 
 // ===== the pair pipeline: whole envs per workgroup, fp32 filters, exact stage on request =====
 enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
 
-// fp32 image of one drone, written to both copies of its env segment.
+// fp32 image of one drone, written to both copies of its env segment (NW > 1: the second copy
+// holds the first N/2 + 1 drones only, see f32_len_nw).
+template <int NW>
 __device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el, int d,
                                           bool active, const double p[3], const double v[3],
                                           const double az[3], double r, double prio) {
@@ -151,8 +153,10 @@ __device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el,
   const int o = el * 2 * P.N + d, os = el * P.N + d;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
-    if (k == WX || k == WY || k == WZ || k == WR) { L.w[k][o] = val[k]; L.w[k][o + P.N] = val[k]; }
-    else L.w[k][os] = val[k];
+    if (k == WX || k == WY || k == WZ || k == WR) {
+      L.w[k][o] = val[k];
+      if (NW == 1 || d <= (P.N >> 1)) L.w[k][o + P.N] = val[k];
+    } else L.w[k][os] = val[k];
   }
   const double cm = (double)P.cold().cmax;
   if (!(__builtin_fabs(cx) <= cm && __builtin_fabs(cy) <= cm && __builtin_fabs(cz) <= cm))

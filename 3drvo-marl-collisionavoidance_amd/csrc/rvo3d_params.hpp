@@ -27,13 +27,11 @@ struct Cold {
   double T5, T04;     // max{x : sqrt(x) <= 5 | 0.4}  (rvo_inter.py:104; drone.py:15)
   double cen[3];      // fp32 candidate filter (stage G): centre,
   double act_scale;   // 10^action_decimals or 0 (no re-quantisation)
-  unsigned long long zf_m40;  // ceil(2^40 / zf_q)
   float cmax;         // |centred coordinate| bound the bands were computed for
   float kdot;         // fp32 error bound of v.rel per unit |v|_1
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
-  uint32_t zf_q;      // 16-B row writer (W even): row bytes / 8
-  uint32_t zf_dr, zf_dq;  // (2 * threads) / zf_q and % zf_q: one lane's step from chunk to chunk
+  uint32_t zf_q;      // 16-B row writer (W even): row bytes / 8, else 0
   int nb;
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)

@@ -81,7 +81,7 @@ __device__ __forceinline__ void write_proprio(const Params& P, int g, const Dron
 
 // 16-B row writer, part 1: the lane's proprioceptive floats go to LDS (float2 [row][6], laid
 // over the fp32 image, which is dead by now) together with the start of the row's zero run in
-// 8-B units; row_fill16() then writes proprio and zeros of all rows with coalesced 16-B stores.
+// 8-B units; row_fill_pairs() then writes proprio and zeros of all rows with coalesced 16-B stores.
 __device__ __forceinline__ void stage_row(const Params& P, const Lds& L, int tid, int g,
                                           const Drone& S, const ProprioTail& t, int kept) {
   const double v[8] = {S.x, S.y, S.z, S.vx, S.vy, S.vz, S.r, S.prio};
@@ -103,73 +103,54 @@ __device__ __forceinline__ void stage_row(const Params& P, const Lds& L, int tid
   if (bad) atomicOr(P.err, 1u);
 }
 
-// 16-B row writer, part 2 (W even, obs 16-B aligned): the rows [row0, row0 + nrows) of this
-// workgroup are one contiguous byte range; every 16-B chunk of it is assembled from two 8-B
-// halves - proprio bytes from LDS, zeros inside a row's zero run, nothing inside the kept VO
-// rows (their lane wrote them) - and stored fully coalesced.  A half outside the range or
-// inside kept rows turns the store into an 8-B one.
-// All index arithmetic is RELATIVE to the workgroup's first 8-B unit (values below
-// 2 * T * q + q, whatever E * N is); only the base pointer is 64-bit.
-__device__ __forceinline__ void row_fill16(const Params& P, const Lds& L, int tid, int row0,
-                                           int nrows) {
-  const uint32_t q = (uint32_t)P.W >> 1;  // 8-B units per row
-  const unsigned long long ustart = (unsigned long long)q * (unsigned)row0;
-  const uint32_t odd = (uint32_t)(ustart & 1ull);  // the range starts in the middle of a chunk
-  const uint32_t ulen = q * (uint32_t)nrows;       // units of this workgroup
-  const uint32_t nchunks = (ulen + odd + 1u) >> 1;
+// 16-B row writer, part 2 (W even, obs 16-B aligned).  Two consecutive rows (an even row and
+// its successor, counted over the whole obs tensor) are 2 * W * 4 = 16 * q bytes starting on a
+// 16-B boundary: q = W / 2 chunks of 16 B.  One wave-instruction stores one row pair: lane c
+// owns chunk c of every pair, i.e. two fixed 8-B units (row of the pair, unit inside the row)
+// computed once; per pair it looks up the zero runs of its one or two rows and assembles the
+// chunk - proprio bytes from LDS, zeros inside a row's zero run, nothing inside the kept VO
+// rows (their lane wrote them).  A half outside the workgroup's rows or inside kept rows turns
+// the store into an 8-B one.  The waves of the workgroup take the pairs round-robin.
+template <int NW>
+__device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, int tid, int row0,
+                                               int nrows) {
+  const int q = P.W >> 1;  // 8-B units per row = 16-B chunks per row pair
+  const int ln = tid & 63, wv = tid >> 6;
+  const int nwv = NW == 1 ? 1 : (L.T >> 6);  // waves of this workgroup (<= NW; T = N rounded up to 64)
+  const int pair0 = row0 >> 1;
+  const int npairs = ((row0 + nrows + 1) >> 1) - pair0;
+  const int rbase = 2 * pair0 - row0;  // local row of the first pair's first row: 0 or -1
   const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
-  // (row, unit inside the row) of this lane's first chunk by one multiplication; the next
-  // chunk of the lane is T chunks = 2T units further: + dr rows, + dq units, one carry
-  const uint32_t dr = P.cold().zf_dr, dq = P.cold().zf_dq;
-  int lrow;      // row of the chunk's first half, relative to row0 (-1: the half chunk in
-  uint32_t o0;   // front of an odd start), and its unit inside that row
-  {
-    const int v = 2 * tid - (int)odd;  // first unit of the lane's first chunk, relative
-    if (v < 0) { lrow = -1; o0 = q - 1; }
-    else {
-      lrow = (int)(((unsigned long long)(uint32_t)v * P.cold().zf_m40) >> 40);
-      o0 = (uint32_t)v - (uint32_t)lrow * q;
-    }
-  }
-  int pidx = lrow * 6;  // float2 index of the row's proprio in LDS (kept incrementally)
-  const int pstep = 6 * (int)dr;
-  char* ptr = reinterpret_cast<char*>(P.obs) + 16ull * ((ustart >> 1) + (unsigned)tid);
-  const size_t pinc = 16ull * (size_t)L.T;
-  // Row indices one outside [0, nrows) occur at the two ends of the range; the LDS words read
-  // for them are valid memory next to the arrays and never used (in0 / in1 are false there).
-  for (uint32_t c = (uint32_t)tid; c < nchunks; c += 4 * L.T) {
-    uint32_t off0[4], off1[4];
-    int z0[4], z1[4];
-    float2 d0[4], d1[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool wrap = o0 + 1 == q;
-      const uint32_t o1 = wrap ? 0u : o0 + 1;
-      const int l1 = lrow + (wrap ? 1 : 0), pidx1 = pidx + (wrap ? 6 : 0);
-      z0[u] = L.kept[lrow]; z1[u] = L.kept[l1];
-      d0[u] = pro2[pidx + (int)(o0 < 5u ? o0 : 5u)];
-      d1[u] = pro2[pidx1 + (int)(o1 < 5u ? o1 : 5u)];
-      off0[u] = o0; off1[u] = o1;
-      o0 += dq; lrow += (int)dr; pidx += pstep;
-      if (o0 >= q) { o0 -= q; lrow += 1; pidx += 6; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t cu = c + u * L.T;
-      const bool live = cu < nchunks;
-      const bool in0 = live & !((odd != 0) & (cu == 0));
-      const bool in1 = live & (2u * cu + 1u - odd < ulen);
-      const bool p0 = off0[u] < 6u, p1 = off1[u] < 6u;
-      const bool v0 = in0 & (p0 | (off0[u] >= (uint32_t)z0[u]));
-      const bool v1 = in1 & (p1 | (off1[u] >= (uint32_t)z1[u]));
-      const float2 a = p0 ? d0[u] : make_float2(0.f, 0.f);
-      const float2 b = p1 ? d1[u] : make_float2(0.f, 0.f);
-      char* const pc = ptr + (size_t)u * pinc;
+  const uint32_t pair_bytes = 8u * (uint32_t)P.W;
+  char* const obsb = reinterpret_cast<char*>(P.obs) + (size_t)pair0 * pair_bytes;
+  // Row indices -1 and nrows occur at the two ends of the range; the LDS words read for them are
+  // valid memory next to the arrays and never used (in0 / in1 are false there).
+  for (int cb = 0; cb < q; cb += 64) {  // one trip unless a row has more than 64 chunks
+    const int c = cb + ln;
+    const bool lane_on = c < q;
+    const int h0 = 2 * c, h1 = 2 * c + 1;        // the chunk's halves, as units of the pair
+    const int s0 = h0 >= q ? 1 : 0, s1 = h1 >= q ? 1 : 0;
+    const int u0 = h0 - (s0 ? q : 0), u1 = h1 - (s1 ? q : 0);
+    const bool p0 = u0 < 6, p1 = u1 < 6;         // proprio units
+    const int pu0 = p0 ? u0 : 5, pu1 = p1 ? u1 : 5;
+    uint32_t off = (uint32_t)wv * pair_bytes + 16u * (uint32_t)c;
+#pragma unroll 4
+    for (int i = wv; i < npairs; i += nwv) {
+      const int lr0 = rbase + 2 * i + s0, lr1 = rbase + 2 * i + s1;
+      const int z0 = L.kept[lr0], z1 = L.kept[lr1];
+      const float2 d0 = pro2[lr0 * 6 + pu0], d1 = pro2[lr1 * 6 + pu1];
+      const bool in0 = lane_on & ((unsigned)lr0 < (unsigned)nrows);
+      const bool in1 = lane_on & ((unsigned)lr1 < (unsigned)nrows);
+      const bool v0 = in0 & (p0 | (u0 >= z0));
+      const bool v1 = in1 & (p1 | (u1 >= z1));
+      const float2 a = p0 ? d0 : make_float2(0.f, 0.f);
+      const float2 b = p1 ? d1 : make_float2(0.f, 0.f);
+      char* const pc = obsb + off;
       if (v0 & v1) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
       else if (v0) *reinterpret_cast<float2*>(pc) = a;
       else if (v1) *reinterpret_cast<float2*>(pc + 8) = b;
+      off += (uint32_t)nwv * pair_bytes;
     }
-    ptr += 4 * pinc;
   }
 }
 
@@ -203,7 +184,7 @@ __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int
   if (bad) atomicOr(P.err, 1u);
 }
 
-// Generic row writer (W odd, or obs not 16-B aligned; the 16-B path is stage_row + row_fill16).
+// Generic row writer (W odd, or obs not 16-B aligned; the 16-B path is stage_row + row_fill_pairs).
 // The zero run behind the kept rows of one observation row: with 8-B zero-fill units an odd
 // 9 * kept leaves one float for this lane.
 __device__ __forceinline__ void publish_zero_run(const Params& P, int g, int kept) {
@@ -329,19 +310,21 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 // One-wave workgroups (N <= 64) are register-limited: 128 VGPRs = 4 waves per SIMD, i.e. the
 // 4096 waves of 64 x 4096 are all resident at once.  Larger N is LDS-limited (3 per SIMD).
 #ifndef RVO3D_WAVES_ATTR
-#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NW == 1 ? 4 : 3)))
+#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((NW == 1 || NFIX >= 128) ? 4 : 3)))
 #endif
 
 // The whole environment step, one launch.
-// NFIX = 64: the instantiation for exactly 64 drones per env (one env per wave): N and the
-// envs per workgroup are compile-time constants, so the index arithmetic of the sweeps folds.
+// NFIX > 0: the instantiation for exactly NFIX drones per env (16, 32, 64: 64 / NFIX envs per
+// one-wave workgroup; 128, 256: one env per workgroup of NFIX threads): N, the envs per
+// workgroup and the workgroup size are compile-time constants, so the LDS layout and the
+// index arithmetic of the sweeps fold.  NFIX = 0: any N <= 64 * NW.
 // TRAIN = rvo_inter.env_train (rvo_inter.py:14), a compile-time constant of the instantiation.
 template <int MODE, int NW, int NFIX = 0, bool TRAIN = true>
 __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params Pin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Params P = Pin;
-  if (NFIX) { P.N = NFIX; P.epb = 64 / NFIX; }
-  const int tid = threadIdx.x, T = NW == 1 ? 64 : (int)blockDim.x, N = P.N;
+  if (NFIX) { P.N = NFIX; P.epb = NFIX <= 64 ? 64 / NFIX : 1; }
+  const int tid = threadIdx.x, T = (NW == 1 || NFIX) ? 64 * NW : (int)blockDim.x, N = P.N;
   const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
   const int el = tid / N;
   const int d = tid - el * N;
@@ -411,7 +394,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   L.r[tid] = S.r; L.prio[tid] = S.prio;
   {
     const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
-    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+    stage_f32<NW>(P, L, el, d, active, p, v, az, S.r, S.prio);
   }
   __syncthreads();
 
@@ -448,7 +431,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     }
     __syncthreads();
-    if (P.zf16) row_fill16(P, L, tid, e0 * N, nrows);
+    if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
     else zero_fill(P, L, tid, e0 * N, nrows);
     return;
   }
@@ -567,7 +550,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   L.vx[tid] = S.vx; L.vy[tid] = S.vy; L.vz[tid] = S.vz;
   {
     const double p[3] = {S.x, S.y, S.z}, v[3] = {S.vx, S.vy, S.vz};
-    stage_f32(P, L, el, d, active, p, v, az, S.r, S.prio);
+    stage_f32<NW>(P, L, el, d, active, p, v, az, S.r, S.prio);
   }
   __syncthreads();
 
@@ -615,7 +598,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       L.x[tid] = S.x; L.y[tid] = S.y; L.z[tid] = S.z;
       L.vx[tid] = 0.0; L.vy[tid] = 0.0; L.vz[tid] = 0.0;
       const double v0[3] = {0, 0, 0};
-      stage_f32(P, L, el, d, true, p, v0, az, S.r, S.prio);
+      stage_f32<NW>(P, L, el, d, true, p, v0, az, S.r, S.prio);
     }
   }
   // everything about this drone except its VO rows is final now.  The stores wait until
@@ -669,7 +652,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   __syncthreads();  // the staged rows / L.kept complete
   if (!RVO3D_ABLATED(16)) {
-    if (P.zf16) row_fill16(P, L, tid, e0 * N, nrows);
+    if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
     else zero_fill(P, L, tid, e0 * N, nrows);
   }
   RVO3D_STAMP(8);

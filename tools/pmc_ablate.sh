@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for AB in 0 1 2 4 7 32 64 8 16 24; do
   export RVO3D_ABLATE=$AB
   timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
-    --output-format csv -d $OUT/a$AB -- python3 $GRAFT_REPO_ROOT/tools/bench_diag.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/a$AB.log 2>&1 || echo "ablate $AB failed" >> $OUT/fail.log
+    --output-format csv -d $OUT/a$AB -- python3 $GRAFT_REPO_ROOT/tools/bench_diag.py --steps 10 --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/a$AB.log 2>&1 || echo "ablate $AB failed" >> $OUT/fail.log
 done
 python3 - <<PY
 import csv, glob, collections

@@ -4,9 +4,10 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcq_$TAG
 mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
+BENCH_ARGS=${BENCH_ARGS:-}
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
-  --output-format csv -d $OUT/p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/p.log 2>&1
+  --output-format csv -d $OUT/p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $OUT/p.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0.0, 0])

@@ -4,9 +4,10 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmct_$TAG
 mkdir -p $OUT
 for kv in "$@"; do export "$kv"; done
+BENCH_ARGS=${BENCH_ARGS:-}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --prewarm 20 --no-cpu-baseline > $OUT/$C.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --prewarm 20 --no-cpu-baseline $BENCH_ARGS > $OUT/$C.log 2>&1
 done
 python3 - <<PY
 import csv, glob

@@ -6,8 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import diaglib  # noqa: F401  the -DRVO3D_DIAG build: the product library has no stamps
 from rvo3d_amd import BatchedDroneEnv, synthetic_actions, synthetic_world, _lib
-E, N = int(os.environ.get("STAMPS_E", 4096)), 64
-env = BatchedDroneEnv(synthetic_world(E, N, (50, 50, 10)), action_decimals=2)
+E, N = int(os.environ.get("STAMPS_E", 4096)), int(os.environ.get("STAMPS_N", 64))
+NB = int(os.environ.get("STAMPS_NB", 0))
+MAP = tuple(float(x) for x in os.environ.get("STAMPS_MAP", "50,50,10").split(","))
+env = BatchedDroneEnv(synthetic_world(E, N, MAP, nb=NB), action_decimals=2)
+print("launch", env.launch_info(), "E", E, "N", N, "nb", NB, "map", MAP)
 acts = [torch.from_numpy(synthetic_actions(E, N, t).astype(np.float32)).cuda() for t in range(12)]
 env.observe()
 for t in range(10):
