@@ -233,7 +233,11 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     const double band = 2.0 * (2.0 * 1.7320508 * 10.5 * eD + 3.0 * eD * eD + 8.0 * u * 110.25);
     C.cmax = (float)cmax;
     P.band = std::nextafter((float)band, INFINITY);
-    P.t10f = std::nextafter((float)(P.T10 + band), INFINITY);
+    // stage G tests the sign of dx^2 + dy^2 + dz^2 - t' (one fma chain): the chain's own rounding
+    // (<= 3 ulp of ~110) is inside the band, which is twice the bound as it is
+    const float t10f = std::nextafter((float)(P.T10 + band), INFINITY);
+    P.t10n = -std::nextafter(t10f, INFINITY);
+    P.bandn = P.band + P.t10n;
     C.kdot = std::nextafter((float)(2.0 * (eD + 4.0 * u * 10.5) * 1.001), INFINITY);
     // stage X1 (wave mode).  With gap = d^2 - R^2 >= x1_gap = 512*band the relative
     // error of gap is <= 1/1024 and |rel| >= sqrt(gap); a direction cosine then

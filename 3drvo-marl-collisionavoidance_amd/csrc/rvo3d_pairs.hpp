@@ -3,6 +3,8 @@
 // Part of the gfx950 device code (see rvo3d_device.hpp for the overview).
 #pragma once
 
+#include <type_traits>
+
 #include "rvo3d_lds.hpp"
 
 namespace rvo3d {
@@ -180,39 +182,56 @@ __device__ __forceinline__ void valid_offsets(int N, int d, uint32_t valid[NW]) 
   }
 }
 
-// Stage G for the offsets of word w (packed fp32, two offsets per instruction): squared
-// distance to neighbour d + k against the threshold(s).  TOUCHONLY: possibly touching
-// (and in range); else: possibly in range.
+// Stage G arithmetic, shared by every place that decides "possibly in range" (gate_word,
+// regate_resets): acc = dx^2 + dy^2 + dz^2 - t', one fma chain starting from -t' with
+// t' = nextafter(T10 + band): the pair is possibly in range iff acc < 0 (d2 < t' <=> d2 <= t10f up to
+// the rounding of the chain, which the doubled band covers), i.e. iff the SIGN BIT of acc is set -
+// one v_alignbit per pair shifts it into the word, no compare / select / or.
+__device__ __forceinline__ float gate_acc(float dx, float dy, float dz, float t10n) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, t10n)));
+}
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t m, float acc) {
+  return __builtin_amdgcn_alignbit(m, __builtin_bit_cast(uint32_t, acc), 31);  // (m << 1) | sign(acc)
+}
+
+// Stage G for the offsets of word w (packed fp32, two offsets per instruction), from the
+// highest offset of the word down, so that bit b of the result is offset 32w + b + 1.
+// TOUCHONLY: possibly touching (and in range), with the in-range word on the side; else:
+// possibly in range.  Bits above the word's last offset may be set: callers mask with valid[].
 template <bool TOUCHONLY>
 __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int o0, int w, int H,
                                               float mex, float mey, float mez, float mer,
                                               uint32_t* range_out = nullptr) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   const v2f sx = {mex, mex}, sy = {mey, mey}, sz = {mez, mez}, sr = {mer, mer};
+  const v2f tn = {P.t10n, P.t10n};
   const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
-  uint32_t m = 0u, mr = 0u;
+  uint32_t mr = 0u, mt = 0u;
 #pragma unroll 8
-  for (int b = 0; b < kend; b += 2) {
+  for (int b = (kend - 1) & ~1; b >= 0; b -= 2) {
     const int o = o0 + 32 * w + b + 1;
     const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;
     const v2f dy = (v2f){L.w[WY][o], L.w[WY][o + 1]} - sy;
     const v2f dz = (v2f){L.w[WZ][o], L.w[WZ][o + 1]} - sz;
-    v2f d2 = dx * dx;
-    d2 = __builtin_elementwise_fma(dy, dy, d2);
-    d2 = __builtin_elementwise_fma(dz, dz, d2);
-    uint32_t b0 = d2.x <= P.t10f, b1 = d2.y <= P.t10f;
+    v2f acc = __builtin_elementwise_fma(dx, dx, tn);
+    acc = __builtin_elementwise_fma(dy, dy, acc);
+    acc = __builtin_elementwise_fma(dz, dz, acc);  // == gate_acc per half
+    mr = shift_in_sign(shift_in_sign(mr, acc.y), acc.x);
     if (TOUCHONLY) {
-      if (range_out) mr |= (b0 | (b1 << 1)) << b;  // the in-range word on the side
+      // possibly touching: d2 <= (r + mr)^2 * 1.00001 + band, as the sign of
+      // (d2 - t') - ((r + mr)^2 * 1.00001 + band - t')
       const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
       const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
-                                               (v2f){P.band, P.band});
-      b0 &= (uint32_t)(d2.x <= rc.x);
-      b1 &= (uint32_t)(d2.y <= rc.y);
+                                               (v2f){P.bandn, P.bandn});
+      const v2f at = acc - rc;
+      mt = shift_in_sign(shift_in_sign(mt, at.y), at.x);
     }
-    m |= (b0 | (b1 << 1)) << b;
   }
-  if (TOUCHONLY && range_out) *range_out = mr;
-  return m;
+  if (TOUCHONLY) {
+    if (range_out) *range_out = mr;
+    return mt & mr;
+  }
+  return mr;
 }
 
 // Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
@@ -247,33 +266,38 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     const bool far = L.far[el] != 0;
     uint32_t valid[NW];
     valid_offsets<NW>(N, d, valid);
+    // stage G for every word, unless the words of this very state are on file (gw in, have_gw)
+    if (ROWS && !TOUCH) RVO3D_STAMP(10);
+    if (!have_gw) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if (ROWS && !TOUCH) RVO3D_STAMP(10);
-      // stage G, unless the words of this very state are on file (gw in, have_gw)
-      uint32_t cand;
-      if (have_gw) cand = gw[w];
-      else {
-        cand = far ? valid[w] : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
-        gw[w] = cand;
-      }
+      for (int w = 0; w < NW; ++w)
+        gw[w] = far ? valid[w] : (gate_word<false>(P, L, o0, w, H, mex, mey, mez, mer) & valid[w]);
+    }
+    if (ROWS && !TOUCH) RVO3D_STAMP(11);
+    // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd count repeats
+    // its last candidate: the requests are idempotent ORs).  Workgroups of several waves walk
+    // 64 offsets per loop (two words): fewer, fuller trips than one loop per word.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
+    const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};
+    const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
+              taz = {2.f * maz, 2.f * maz};
+    const int fr = far ? 1 : 0;
+    constexpr int CW = NW == 1 ? 1 : 2;  // words per candidate loop
+#pragma unroll
+    for (int w = 0; w < NW / CW; ++w) {
+      typedef typename std::conditional<CW == 1, uint32_t, unsigned long long>::type cand_t;
+      cand_t cand = CW == 1 ? (cand_t)gw[0]
+                            : (cand_t)((unsigned long long)gw[CW * w] |
+                                       ((unsigned long long)gw[CW * w + (CW - 1)] << 32));
       if (RVO3D_ABLATED(64)) cand = 0;
-      if (ROWS && !TOUCH) RVO3D_STAMP(11);
-      // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd
-      // count repeats its last candidate: the requests are idempotent ORs)
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
-      const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};
-      const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
-                taz = {2.f * maz, 2.f * maz};
-      const int fr = far ? 1 : 0;
       while (cand) {
-        const int kb0 = __builtin_ctz(cand);
+        const int kb0 = CW == 1 ? __builtin_ctz((uint32_t)cand) : __builtin_ctzll(cand);
         cand &= cand - 1;
-        const bool two = cand != 0u;
-        const int kb1 = two ? __builtin_ctz(cand) : kb0;
+        const bool two = cand != 0;
+        const int kb1 = two ? (CW == 1 ? __builtin_ctz((uint32_t)cand) : __builtin_ctzll(cand)) : kb0;
         cand &= cand - 1;
-        const int off0 = 32 * w + kb0 + 1, off1 = 32 * w + kb1 + 1;
+        const int off0 = 32 * CW * w + kb0 + 1, off1 = 32 * CW * w + kb1 + 1;
         const int oa = o0 + off0, ob = o0 + off1;
         int jd0 = d + off0, jd1 = d + off1;
         if (jd0 >= N) jd0 -= N;
@@ -472,11 +496,8 @@ __device__ __forceinline__ uint32_t regate_resets(const Params& P, const Lds& L,
     const int rel = __builtin_amdgcn_readlane(el, rl), rd = __builtin_amdgcn_readlane(d, rl);
     const int orr = rel * 2 * N + rd;
     const float dx = L.w[WX][orr] - mex, dy = L.w[WY][orr] - mey, dz = L.w[WZ][orr] - mez;
-    float d2 = dx * dx;
-    d2 = __builtin_fmaf(dy, dy, d2);
-    d2 = __builtin_fmaf(dz, dz, d2);
     const bool same = active && el == rel && tid != rl;
-    const bool inr = same && d2 <= P.t10f;
+    const bool inr = same && __builtin_signbit(gate_acc(dx, dy, dz, P.t10n));
     int k = rd - d;  // offset from me to r
     if (k < 0) k += N;
     if (same && k >= 1 && k <= H) {  // I own the pair (if the offset is mine at all)

@@ -58,7 +58,8 @@ struct Params {
   int zf16;           // per call: obs is 16-B aligned and W is even -> 16-B zero-fill
   double T10;         // max{x : sqrt(x) <= 10}  (rvo_inter.py:96)
   // fp32 candidate filter (stage G): error bands
-  float t10f;      // T10 + band, rounded up
+  float t10n;      // -nextafter(T10 + band): stage G's fma chain starts here, in range iff it ends < 0
+  float bandn;     // band + t10n: the same start for the "possibly touching" threshold of stage G
   float band;      // fp32 error bound of a squared distance at <= 10.5 m
   // fp32 cone pre-filter (stage X1)
   int nw;          // ceil(N / 64) rounded up to a power of two: words per request mask
@@ -130,7 +131,7 @@ struct Params {
   const Cold* cold_;   // device copy of the rarely used parameters
   __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
 #ifdef RVO3D_DIAG
-  unsigned long long* dbg;  // diagnostics build only: per-workgroup s_memtime stamps [blocks][16], or null
+  unsigned long long* dbg;  // diagnostics build only: per-workgroup s_memtime stamps [blocks][24], or null
 #endif
   // per-call I/O
   const void* actions;
@@ -147,7 +148,7 @@ struct Params {
 #ifdef RVO3D_DIAG
 #define RVO3D_STAMP(i)                                                                  \
   do {                                                                                  \
-    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define RVO3D_ABLATED(bits) ((P.ablate & (bits)) != 0)
 #else

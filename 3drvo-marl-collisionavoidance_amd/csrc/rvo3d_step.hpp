@@ -134,25 +134,64 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
     const bool p0 = u0 < 6, p1 = u1 < 6;         // proprio units
     const int pu0 = p0 ? u0 : 5, pu1 = p1 ? u1 : 5;
     uint32_t off = (uint32_t)wv * pair_bytes + 16u * (uint32_t)c;
-#pragma unroll 4
-    for (int i = wv; i < npairs; i += nwv) {
-      const int lr0 = rbase + 2 * i + s0, lr1 = rbase + 2 * i + s1;
-      const int z0 = L.kept[lr0], z1 = L.kept[lr1];
-      const float2 d0 = pro2[lr0 * 6 + pu0], d1 = pro2[lr1 * 6 + pu1];
-      const bool in0 = lane_on & ((unsigned)lr0 < (unsigned)nrows);
-      const bool in1 = lane_on & ((unsigned)lr1 < (unsigned)nrows);
-      const bool v0 = in0 & (p0 | (u0 >= z0));
-      const bool v1 = in1 & (p1 | (u1 >= z1));
-      const float2 a = p0 ? d0 : make_float2(0.f, 0.f);
-      const float2 b = p1 ? d1 : make_float2(0.f, 0.f);
-      char* const pc = obsb + off;
-      if (v0 & v1) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
-      else if (v0) *reinterpret_cast<float2*>(pc) = a;
-      else if (v1) *reinterpret_cast<float2*>(pc + 8) = b;
-      off += (uint32_t)nwv * pair_bytes;
+    const uint32_t ostep = (uint32_t)nwv * pair_bytes;
+    // four pairs per trip: their LDS lookups are issued together (one round trip, not four)
+    // and the stores are two flat predicated regions (whole chunk: nearly always; one half:
+    // only next to kept rows and at the ends of the range)
+    for (int i0 = wv; i0 < npairs; i0 += 4 * nwv) {
+      int z0[4], z1[4];
+      float2 d0[4], d1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nwv;  // may run past npairs: reads stay inside the LDS allocation
+        const int lr0 = rbase + 2 * i + s0, lr1 = rbase + 2 * i + s1;
+        z0[u] = L.kept[lr0]; z1[u] = L.kept[lr1];
+        d0[u] = pro2[lr0 * 6 + pu0]; d1[u] = pro2[lr1 * 6 + pu1];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * nwv;
+        const int lr0 = rbase + 2 * i + s0, lr1 = rbase + 2 * i + s1;
+        bool live = lane_on & (i < npairs);
+#ifdef RVO3D_DIAG
+        if (RVO3D_ABLATED(128)) live &= (p0 | p1);
+#endif
+        const bool v0 = live & ((unsigned)lr0 < (unsigned)nrows) & (p0 | (u0 >= z0[u]));
+        const bool v1 = live & ((unsigned)lr1 < (unsigned)nrows) & (p1 | (u1 >= z1[u]));
+        const float2 a = p0 ? d0[u] : make_float2(0.f, 0.f);
+        const float2 b = p1 ? d1[u] : make_float2(0.f, 0.f);
+        char* const pc = obsb + (off + (uint32_t)u * ostep);
+        if (v0 & v1) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
+        if (v0 != v1) *reinterpret_cast<float2*>(pc + (v1 ? 8 : 0)) = v1 ? b : a;
+      }
+      off += 4u * ostep;
     }
   }
 }
+
+#ifdef RVO3D_DIAG
+// EXPERIMENT (diagnostics build, RVO3D_ABLATE bit 128; results invalid for rows with kept VO
+// rows): zeros of every chunk that lies wholly inside a VO region, issued before the final sweep.
+template <int NW>
+__device__ __forceinline__ void early_zero_fill(const Params& P, const Lds& L, int tid, int row0, int nrows) {
+  const int q = P.W >> 1;
+  const int ln = tid & 63, wv = tid >> 6;
+  const int nwv = NW == 1 ? 1 : (L.T >> 6);
+  const int pair0 = row0 >> 1;
+  const int npairs = ((row0 + nrows + 1) >> 1) - pair0;
+  const uint32_t pair_bytes = 8u * (uint32_t)P.W;
+  char* const obsb = reinterpret_cast<char*>(P.obs) + (size_t)pair0 * pair_bytes;
+  const int c = ln;
+  const int h0 = 2 * c, h1 = 2 * c + 1;
+  const int u0 = h0 - (h0 >= q ? q : 0), u1 = h1 - (h1 >= q ? q : 0);
+  const bool mine = c < q && u0 >= 6 && u1 >= 6;
+  uint32_t off = (uint32_t)wv * pair_bytes + 16u * (uint32_t)c;
+  for (int i = wv; i < npairs; i += nwv) {
+    if (mine) *reinterpret_cast<float4*>(obsb + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+    off += (uint32_t)nwv * pair_bytes;
+  }
+}
+#endif
 
 // The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
 // iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
@@ -472,6 +511,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     }
     rew_k = rvo_reward_k(rvo_reward_pre(dv, a), flag, tmin);
   }
+  RVO3D_STAMP(18);
   __syncthreads();  // everyone is done with the pre-move LDS image
   if (active) {
     double prev[3];
@@ -536,6 +576,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     const double exlen = real_len - route_len + 4;
     mov_nc = mov_reward_k(P, false, arrive_r, waypoint_num, npts - 1, dest_r, dev, exlen > 0,
                           exlen);
+    RVO3D_STAMP(19);
     collision = building_hit(P, S);
     if (S.x < 0 || S.x > P.cold().map[0] || S.y < 0 || S.y > P.cold().map[1] || S.z < 0 || S.z > P.cold().map[2])
       collision = true;  // drone.drone_out_map, drone.py:213-225
@@ -634,6 +675,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       have_gw2 = true;
     }
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
+#ifdef RVO3D_DIAG
+    if (RVO3D_ABLATED(128)) early_zero_fill<NW>(P, L, tid, e0 * N, nrows);
+#endif
     kept = sweep_env<NW, true, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
@@ -645,12 +689,14 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   if (active) {
     if (!RVO3D_ABLATED(8)) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
+      RVO3D_STAMP(16);
       if (P.zf16) stage_row(P, L, tid, g, S, ptail, kept);
       else { write_proprio(P, g, S, ptail); publish_zero_run(P, g, kept); }
     }
     if (!P.zf16) L.kept[tid] = kept;
   }
   __syncthreads();  // the staged rows / L.kept complete
+  RVO3D_STAMP(17);
   if (!RVO3D_ABLATED(16)) {
     if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
     else zero_fill(P, L, tid, e0 * N, nrows);

@@ -16,7 +16,7 @@ env.observe()
 for t in range(10):
     env.step(acts[t], autoreset=True)
 nb = env.launch_info()["blocks"]
-buf = torch.zeros((nb, 16), dtype=torch.int64, device="cuda")
+buf = torch.zeros((nb, 24), dtype=torch.int64, device="cuda")
 _lib.check(_lib.lib().rvo3d_debug_stamps(env._h, C.c_void_p(buf.data_ptr())), "stamps")
 env.step(acts[10], autoreset=True)
 torch.cuda.synchronize()
@@ -27,6 +27,11 @@ print("phase mean / p50 / p95 cycles (s_memtime ticks):")
 for i, n in enumerate(names):
     print(f"  {n:16s} {d[:, i].mean():9.0f} {np.median(d[:, i]):9.0f} {np.percentile(d[:, i], 95):9.0f}")
 
+if s[:, 16:20].any():
+    print(f"  integrate: loads + rvo reward {(s[:, 18] - s[:, 3]).mean():8.0f}  barrier + state loads + kinematics + dronestate + mov reward "
+          f"{(s[:, 19] - s[:, 18]).mean():8.0f}  buildings + map + stores + restage {(s[:, 4] - s[:, 19]).mean():8.0f}")
+    print(f"  rows phase: kept VO rows {(s[:, 16] - s[:, 7]).mean():8.0f}  stage_row + barrier {(s[:, 17] - s[:, 16]).mean():8.0f}  "
+          f"row fill {(s[:, 8] - s[:, 17]).mean():8.0f}")
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
 
