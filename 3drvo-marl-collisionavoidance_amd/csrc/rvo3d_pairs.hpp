@@ -194,6 +194,9 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t m, float acc) {
   return __builtin_amdgcn_alignbit(m, __builtin_bit_cast(uint32_t, acc), 31);  // (m << 1) | sign(acc)
 }
 
+#ifndef RVO3D_G_UNROLL
+#define RVO3D_G_UNROLL 8
+#endif
 // Stage G for the offsets of word w (packed fp32, two offsets per instruction), from the
 // highest offset of the word down, so that bit b of the result is offset 32w + b + 1.
 // TOUCHONLY: possibly touching (and in range), with the in-range word on the side; else:
@@ -207,7 +210,7 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
   const v2f tn = {P.t10n, P.t10n};
   const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
   uint32_t mr = 0u, mt = 0u;
-#pragma unroll 8
+#pragma unroll RVO3D_G_UNROLL
   for (int b = (kend - 1) & ~1; b >= 0; b -= 2) {
     const int o = o0 + 32 * w + b + 1;
     const v2f dx = (v2f){L.w[WX][o], L.w[WX][o + 1]} - sx;

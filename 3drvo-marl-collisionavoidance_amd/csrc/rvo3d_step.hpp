@@ -32,10 +32,27 @@ __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
     int ix = (int)__builtin_floor(S.x * inv), iy = (int)__builtin_floor(S.y * inv);
     ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
     iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
-    const uint16_t* const cell = P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1);
-    const int cnt = cell[0];
+    // the cell's whole list in two 16-B loads (kBgridK + 1 = 16 u16, 32-B aligned), then the
+    // records of up to four listed buildings per round trip (index 0 pads the batch: testing
+    // a building twice changes nothing)
+    const uint4* const cell4 = reinterpret_cast<const uint4*>(
+        P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1));
+    const uint4 c0 = cell4[0], c1 = cell4[1];
+    const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const int cnt = (int)(cw[0] & 0xffffu);
     if (cnt != 0xffff) {
-      for (int k = 0; k < cnt; ++k) hit |= building_test(bld, cell[1 + k], S, T5);
+      // entry k (1-based: 1..cnt) is halfword k of the 16
+#define RVO3D_CELL_IDX(k) ((int)((cw[(k) >> 1] >> (((k) & 1) * 16)) & 0xffffu))
+#pragma unroll
+      for (int k0 = 1; k0 <= kBgridK; k0 += 4) {
+        if (k0 > cnt) break;
+        int bi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bi[u] = (k0 + u <= cnt && k0 + u <= kBgridK) ? RVO3D_CELL_IDX(k0 + u) : RVO3D_CELL_IDX(1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hit |= building_test(bld, bi[u], S, T5);
+      }
+#undef RVO3D_CELL_IDX
       return hit;
     }
   }
