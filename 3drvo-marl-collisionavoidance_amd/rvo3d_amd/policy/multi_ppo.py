@@ -17,14 +17,29 @@ Path-cut rules of the reference (multi_ppo.py:226-281), per env:
 GAE follows multi_PPObuf.finish_path (:68-77) in float64 (np.append promotes the
 float32 buffers) and is stored as float32.
 
-Multi-GPU: envs are sharded one process per GPU; the only
-collectives are one all-reduce of the flattened gradient bucket per optimizer step
-and the mean of the KL estimate (so every rank leaves the policy loop together).
+Update modes (`update`, multi_ppo.py:341-376):
+  * reference order (`reference_order=True`, or `update(data_list)` with the reference's own
+    per-agent list): the agents are visited in the order of a seeded np.random.shuffle, at
+    most `max_update_num` of them; each visit is <= train_pi_iters policy steps (KL check
+    BEFORE the step) followed by train_v_iters value steps on that agent's samples alone.
+    With E envs an "agent" is drone n of every env.  Pinned by tests/golden/ppo_update.npz,
+    produced by the reference's update() itself.
+  * pooled (default, the fast path): ONE pass over all T*E*N samples (optionally in
+    minibatches).  A deliberate deviation: the per-agent sequential passes are up to
+    max_update_num * (train_pi_iters + train_v_iters) optimizer steps on N-times smaller
+    batches.  `max_update_num` has no meaning here; passing it without reference_order warns.
+
+Multi-GPU: envs are sharded one process per GPU with EQUAL shards (checked at
+construction: unequal shards would run different numbers of minibatches and hang in the
+collective); the only collectives are one all-reduce of the flattened gradient bucket per
+optimizer step and the mean of the KL estimate (so every rank leaves the policy loop
+together); rank 0 alone writes checkpoints.
 """
 from __future__ import annotations
 
 import os
 import time
+import warnings
 
 import numpy as np
 import torch
@@ -94,7 +109,8 @@ class RolloutBuffer:
         self.cut.zero_()
         flat = lambda x: x.reshape((-1,) + x.shape[3:])
         return dict(obs=flat(self.obs[:self.T]), cnt=flat(self.cnt[:self.T]), act=flat(self.act),
-                    ret=flat(ret), adv=flat(adv), logp=flat(self.logp))
+                    ret=flat(ret), adv=flat(adv), logp=flat(self.logp),
+                    shape=tuple(self.rew.shape))  # (T, E, N): rows are ordered t, e, n
 
 
 class multi_ppo:
@@ -104,8 +120,8 @@ class multi_ppo:
                  render_freq=20, con_train=False, seed=7, save_freq=50, save_figure=False,
                  save_path="test/", save_name="test", load_fname=None, use_gpu=True,
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
-                 max_update_num=10, mpi=False, figure_save_path=None, minibatch_size=None,
-                 dist=None, sanitize_rewards=True, amp=False, **kwargs):
+                 max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
+                 dist=None, sanitize_rewards=True, amp=False, reference_order=False, **kwargs):
         torch.manual_seed(seed)
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
@@ -128,6 +144,12 @@ class multi_ppo:
         self.train_v_iters, self.target_kl = train_v_iters, target_kl
         self.save_freq, self.save_path, self.save_name = save_freq, save_path, save_name
         self.use_gpu, self.minibatch_size = use_gpu, minibatch_size
+        self.reference_order = bool(reference_order)
+        if max_update_num is not None and not self.reference_order:
+            warnings.warn("max_update_num only applies to the reference-order update "
+                          "(reference_order=True or update(data_list)); the pooled update ignores it")
+        self.max_update_num = 10 if max_update_num is None else int(max_update_num)  # multi_ppo.py:101
+        self._check_equal_shards()
         # The reference's RVO reward is inf / nan while a drone sits within 0.4 m of its
         # waypoint (ir_gym.py:88, survey Q9) and would poison GAE; by default such rewards
         # enter the buffer as 0 (set sanitize_rewards=False for the literal behaviour).
@@ -206,6 +228,23 @@ class multi_ppo:
         return self.log
 
     # ---- update -------------------------------------------------------------------------
+    def _world(self):
+        d = self.dist
+        return d.get_world_size() if (d is not None and d.is_initialized()) else 1
+
+    def _check_equal_shards(self):
+        """Every rank must own the same number of samples per epoch: the ranks run the same
+        number of optimizer steps (one collective each) and the gradients are averaged
+        unweighted."""
+        if self._world() == 1:
+            return
+        n = torch.tensor([self.E * self.N, -(self.E * self.N)], dtype=torch.int64, device=self.device)
+        self.dist.all_reduce(n, op=self.dist.ReduceOp.MAX)
+        if int(n[0]) != -int(n[1]):
+            raise ValueError(f"ranks own different shard sizes (max {int(n[0])}, min {-int(n[1])} "
+                             "drones): shard the envs equally (sharding.shard_env_range needs a "
+                             "total divisible by the world size)")
+
     def _allreduce_grads(self):
         d = self.dist
         if d is None or not d.is_initialized() or d.get_world_size() == 1:
@@ -237,6 +276,20 @@ class multi_ppo:
                 yield perm[i:i + mb]
 
     def update(self, data):
+        """multi_ppo.update (multi_ppo.py:341-376).  `data`: the flattened rollout of
+        RolloutBuffer.get(), or - the reference's own signature - a list with one buffer dict
+        per agent (obs = ragged list or padded `obs` + `cnt`)."""
+        if isinstance(data, (list, tuple)):
+            return self._update_reference_order(list(data))
+        if self.reference_order:
+            T, E, N = data["shape"]
+            per_agent = []
+            for r in range(N):  # agent r = drone r of every env, all steps
+                pick = lambda x: x.reshape((T, E, N) + tuple(x.shape[1:]))[:, :, r].reshape(
+                    (T * E,) + tuple(x.shape[1:]))
+                per_agent.append({k: pick(v) for k, v in data.items() if k != "shape"})
+            return self._update_reference_order(per_agent)
+        data = {k: v for k, v in data.items() if k != "shape"}
         n = data["adv"].shape[0]
         kl, pi_steps = 0.0, 0
         for i in range(self.train_pi_iters):  # multi_ppo.py:355-368
@@ -267,6 +320,42 @@ class multi_ppo:
                 self.vf_optimizer.step()
         return dict(kl=kl, pi_steps=pi_steps, loss_v=float(loss_v.detach()))
 
+    def _update_reference_order(self, data_list):
+        """The reference's update, statement by statement (multi_ppo.py:341-376): shuffled
+        agent order from numpy's global generator (seeded in the constructor, as the
+        reference's is: every rank draws the same order), max_update_num, per-agent policy
+        loop with the KL stop before the step, then the per-agent value loop."""
+        randn = np.arange(len(data_list))
+        np.random.shuffle(randn)
+        update_num, kl, loss_v = 0, 0.0, torch.zeros(())
+        pi_steps = []
+        for r in randn:
+            data = data_list[r]
+            update_num += 1
+            if update_num > self.max_update_num:
+                continue
+            steps = 0
+            for i in range(self.train_pi_iters):
+                self.pi_optimizer.zero_grad()
+                loss_pi, pi_info = self.compute_loss_pi(data)
+                kl = self._mean_over_ranks(pi_info["kl"])
+                if kl > self.target_kl:
+                    break
+                loss_pi.backward()
+                self._allreduce_grads()
+                torch.nn.utils.clip_grad_norm_(self.ac.parameters(), max_norm=2.0)
+                self.pi_optimizer.step()
+                steps += 1
+            pi_steps.append(steps)
+            for i in range(self.train_v_iters):
+                self.vf_optimizer.zero_grad()
+                loss_v = self.compute_loss_v(data)
+                loss_v.backward()
+                self._allreduce_grads()
+                self.vf_optimizer.step()
+        return dict(kl=kl, pi_steps=pi_steps, order=[int(x) for x in randn],
+                    loss_v=float(loss_v.detach()))
+
     def _obs_arg(self, data):
         return (data["obs"], data["cnt"]) if "cnt" in data else data["obs"]
 
@@ -286,8 +375,15 @@ class multi_ppo:
         return loss_pi, dict(kl=approx_kl, ent=ent, cf=clipfrac)
 
     def save_model(self, index=0):  # multi_ppo.py:406-420
+        d = self.dist
+        multi = self._world() > 1
+        if multi and d.get_rank() != 0:  # replicas are identical: rank 0 alone writes
+            d.barrier()
+            return
         os.makedirs(self.save_path, exist_ok=True)
         state = dict(model_state=self.ac.state_dict(), pi_optimizer=self.pi_optimizer.state_dict(),
                      vf_optimizer=self.vf_optimizer.state_dict())
         torch.save(self.ac, os.path.join(self.save_path, f"{self.save_name}_{index}.pt"))
         torch.save(state, os.path.join(self.save_path, f"{self.save_name}_check_point_{index}.pt"))
+        if multi:
+            d.barrier()  # nobody reads the files before they are complete

@@ -19,9 +19,15 @@ def rank_info():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+SEED_STRIDE = 1_000_003  # > any per-world key offset (synthetic_world draws buildings from key + 1)
+
+
 def shard_seed(base_seed: int, rank: int) -> int:
-    """Seed of rank's shard: shards are disjoint Philox keys (worlds.synthetic_world)."""
-    return int(base_seed) + int(rank)
+    """Seed of rank's shard.  worlds.synthetic_world uses Philox key `seed` (counter = env) for
+    the routes and key `seed + 1` for the buildings, synthetic_actions key `seed + 7`: a stride
+    of 1 between ranks would give rank r's buildings the key and counter of rank r+1's env 0.
+    Ranks are a large prime stride apart, so no two keys of different shards coincide."""
+    return int(base_seed) + SEED_STRIDE * int(rank)
 
 
 def shard_env_range(total_envs: int, rank: int, world: int):

@@ -135,6 +135,62 @@ def test_losses_and_gradients_match_reference():
                                rtol=1e-3, atol=1e-6)
 
 
+def _update_case(fx, case, device="cpu", as_list=False):
+    """Run our multi_ppo.update on the fixture's per-agent buffers; returns (trainer, stats)."""
+    ac = rnn_ac(None, _Space(), 12, 9, 16, (24, 24), (24, 24), torch.nn.ReLU, torch.nn.Tanh,
+                torch.nn.Identity, use_gpu=False, rnn_mode="biGRU")
+    ac.load_state_dict({k[3:]: torch.as_tensor(v) for k, v in fx.items() if k.startswith("w0:")},
+                       strict=True)
+    ac = ac.to(device)
+    N, T = fx["adv"].shape
+
+    class Env:
+        E, W = 1, 102
+    Env.N, Env.device = N, torch.device(device)
+    tr = multi_ppo(Env(), ac, pi_lr=float(fx["pi_lr"]), vf_lr=float(fx["vf_lr"]), steps_per_epoch=T,
+                   train_pi_iters=int(fx["train_pi_iters"]), train_v_iters=int(fx["train_v_iters"]),
+                   target_kl=float(fx["target_kl"]), clip_ratio=float(fx["clip_ratio"]),
+                   max_update_num=int(fx["max_update_num" + case]), reference_order=True,
+                   seed=int(fx["np_seed"]), use_gpu=False)
+    dev = lambda a: torch.as_tensor(a).to(device)
+    if as_list:  # the reference's own calling convention: one dict per agent, ragged obs lists
+        data = []
+        for n in range(N):
+            obs = [dev(fx["obs"][n, t, :12 + 9 * max(int(fx["count"][n, t]), 1)]) for t in range(T)]
+            data.append(dict(obs=obs, act=dev(fx["act"][n]), ret=dev(fx["ret"][n]), adv=dev(fx["adv"][n]),
+                             logp=dev(fx["logp"][n])))
+    else:        # the flattened [T, E, N] rollout of RolloutBuffer.get()
+        tn = lambda a: dev(np.ascontiguousarray(np.swapaxes(a, 0, 1)).reshape((T * N,) + a.shape[2:]))
+        data = dict(obs=tn(fx["obs"]), cnt=tn(fx["count"]), act=tn(fx["act"]), ret=tn(fx["ret"]),
+                    adv=tn(fx["adv"]), logp=tn(fx["logp"]), shape=(T, 1, N))
+    return tr, tr.update(data)
+
+
+@pytest.mark.parametrize("case,as_list", [("1", False), ("2", False), ("1", True)])
+def test_update_reproduces_the_references_update(case, as_list):
+    """8(f) row 2: multi_ppo.update of the reference itself (multi_ppo.py:341-376, fixture from
+    oracle/gen_golden_ppo_update.py): shuffled agent order, max_update_num (case 2: only two
+    agents are visited), the KL stop before the step (agent 0 stops after 3 policy steps), Adam
+    on pi and v with the shared reader: the parameters after the update match."""
+    fx = load(os.path.join(GOLDEN, "ppo_update.npz"))
+    tr, st = _update_case(fx, case, as_list=as_list)
+    assert st["order"] == fx["order" + case].tolist()
+    assert st["pi_steps"] == fx["pi_steps" + case].tolist()
+    assert (fx["pi_steps1"] == [6, 6, 3, 6]).all() and len(fx["pi_steps2"]) == 2
+    got = tr.ac.state_dict()
+    moved = 0.0
+    for k, v in got.items():
+        want = fx[f"w{case}:" + k]
+        np.testing.assert_allclose(v.numpy(), want, rtol=2e-4, atol=2e-6, err_msg=k)
+        moved = max(moved, float(np.abs(want - fx["w0:" + k]).max()))
+    assert moved > 1e-3  # the update really moved the weights
+
+
+def test_pooled_update_warns_about_max_update_num():
+    with pytest.warns(UserWarning, match="max_update_num"):
+        multi_ppo(_FakeEnv(), mlp_ac(21, hidden_sizes=(8, 8)), steps_per_epoch=2, max_update_num=3)
+
+
 def test_mlp_ac_surface():
     ac = mlp_ac(102)
     obs = torch.randn(5, 102)
@@ -168,6 +224,40 @@ def _ddp_worker(rank, world, port, q):
     q.put((rank, torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _unequal_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group("gloo")
+
+    class Env:
+        N, W, device = 2, 21, torch.device("cpu")
+    Env.E = 3 + rank  # unequal shards
+    try:
+        multi_ppo(Env(), mlp_ac(21, hidden_sizes=(8, 8)), steps_per_epoch=2, dist=dist)
+        q.put((rank, "no error"))
+    except ValueError as ex:
+        q.put((rank, str(ex)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_shards_are_rejected():
+    """Ranks with different shard sizes would run different numbers of optimizer steps and hang
+    in the gradient all-reduce: the constructor refuses them on every rank."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_unequal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all("different shard sizes" in v for v in out.values()), out
 
 
 def test_gradient_allreduce_keeps_ranks_identical():
