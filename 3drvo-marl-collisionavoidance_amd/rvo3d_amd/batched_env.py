@@ -41,6 +41,7 @@ class BatchedDroneEnv:
         self.nm = int(neighbors_num)
         self.W = 12 + 9 * self.nm
         self.acceler = acceler  # ir_gym.acceler (ir_gym.py:34), used by the trainer glue
+        self.env_train = bool(env_train)  # rvo_inter.env_train (rvo_inter.py:14)
         self.world = world
         L = _lib.lib()
         cfg = _lib.Config(self.E, self.N, self.P, int(world.buildings.shape[0]), self.nm,

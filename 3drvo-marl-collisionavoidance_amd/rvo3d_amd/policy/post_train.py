@@ -13,8 +13,13 @@ Reference semantics kept:
   * results: success rate over `num_episodes`, mean / std episode length of the "arrived"
     episodes and mean / std of the per-episode mean speed, np.round(., 2) (:116-128), one line
     appended to result_path + result_name.
-With E envs in parallel the first `num_episodes` episodes to end are counted (ties in env
-order); E = 1 reproduces the reference's sequential loop.
+With E envs in parallel every env contributes the same number of episodes: its first
+ceil(num_episodes / E) ones (counting "the first num_episodes episodes to end" over all envs
+would favour short episodes - collisions - and bias every statistic).  The statistics are over
+those E * ceil(num_episodes / E) episodes; E = 1 is the reference's sequential loop exactly
+(pinned by tests/golden/post_train_*.npz, produced by the reference's policy_test itself).
+A "math domain error" (env_train=False: the reference's evaluator aborts when two drones
+approach inside r + mr, vel_obs3D.py:13) is raised at the end of the step it happens in.
 """
 from __future__ import annotations
 
@@ -73,7 +78,11 @@ class post_train:
         speed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
         n = sn = 0
         ep_len_list, mean_speed_list, ep_ret_list = [], [], []
-        while n < self.num_episodes:
+        quota = -(-self.num_episodes // E)   # episodes counted per env
+        counted = [0] * E
+        total = quota * E
+        check_domain = not getattr(env, "env_train", True)
+        while n < total:
             if act_fn is not None:
                 a = act_fn(obs.view(-1, env.W), cnt.view(-1)).view(E, N, 3)
                 # np.round(float32, 2) = rint(a * 100) / 100 with a TRUE division (a tensor
@@ -88,6 +97,8 @@ class post_train:
             ep_ret += rew[:, 0].double()                                   # r[0] (post_train.py:82)
             ep_len += 1
             ended = done.bool().any(dim=1) | (ep_len == self.max_ep_len) | fin.bool().all(dim=1)
+            if check_domain and (env.error_flags() & 2):
+                raise ValueError("math domain error")  # the reference's drone_step raised here
             if bool(ended.any()):
                 arrived = info.bool().all(dim=1)
                 success = fin.bool().all(dim=1)
@@ -95,8 +106,9 @@ class post_train:
                 el, sp, er = ep_len.cpu().numpy(), (speed_sum / ep_len.double()).cpu().numpy(), ep_ret.cpu().numpy()
                 ar, su = arrived.cpu().numpy(), success.cpu().numpy()
                 for e in idx:
-                    if n >= self.num_episodes:
-                        break
+                    if counted[e] >= quota:
+                        continue  # this env has delivered its share; it keeps stepping, uncounted
+                    counted[e] += 1
                     if ar[e]:
                         ep_len_list.append(int(el[e]))
                     if self.inf_print:
@@ -116,7 +128,7 @@ class post_train:
         std_len = 0 if not ep_len_list else np.round(np.std(ep_len_list), 2)
         average_speed = np.round(np.mean(mean_speed_list), 2)
         std_speed = np.round(np.std(mean_speed_list), 2)
-        line = ("policy_name: " + policy_name + "  successful rate: {:.2%}".format(sn / self.num_episodes)
+        line = ("policy_name: " + policy_name + "  successful rate: {:.2%}".format(sn / total)
                 + " average EpLen: %s std length %s average speed: %s std speed %s"
                 % (mean_len, std_len, average_speed, std_speed))
         if result_path is not None:
@@ -124,6 +136,6 @@ class post_train:
                 print(line, file=f)
         if self.inf_print:
             print(line)
-        return dict(success_rate=sn / self.num_episodes, mean_len=float(mean_len), std_len=float(std_len),
+        return dict(success_rate=sn / total, mean_len=float(mean_len), std_len=float(std_len),
                     average_speed=float(average_speed), std_speed=float(std_speed),
                     episodes=n, ep_ret=ep_ret_list, ep_len=ep_len_list, speed=mean_speed_list)

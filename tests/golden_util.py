@@ -9,7 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def scenario_files():
-    skip = ("calls_", "policy_", "ppo_", "rvo_")  # call-level and policy/PPO vectors have their own tests
+    skip = ("calls_", "policy_", "ppo_", "rvo_", "post_train_")  # call-level and policy/PPO vectors have their own tests
     return sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz"))
                   if not os.path.basename(f).startswith(skip))
 

@@ -478,53 +478,73 @@ def test_training_loop_end_to_end(kind, tmp_path):
     env.close()
 
 
-def test_post_train_policy_test_matches_a_sequential_restatement():
-    """post_train.policy_test (post_train.py:38-128) batched over E envs == the reference's
-    loop restated in numpy on the oracle, episode by episode (same scripted policy output)."""
+class _TablePolicy:
+    """Scripted stand-in for the actor-critic: replays rows of an action table (float32 [steps,
+    N, 3]); env e starts at row start[e].  Same role as the generator's get_action."""
+
+    def __init__(self, table, starts):
+        pad = np.zeros((4096,) + table.shape[1:], np.float32)
+        self.table = torch.from_numpy(np.concatenate([table, pad])).cuda()
+        self.starts = list(starts)
+        self.t = 0
+
+    def eval(self):
+        return self
+
+    def step_tensors(self, obs, std_factor=1):
+        rows = torch.stack([self.table[s + self.t] for s in self.starts])   # [E, N, 3]
+        self.t += 1
+        return rows.view(-1, 3), None, None
+
+
+POST_TRAIN = sorted(f for f in os.listdir(os.path.join(_ROOT, "tests", "golden")) if f.startswith("post_train_"))
+
+
+@pytest.mark.parametrize("name", POST_TRAIN)
+def test_post_train_matches_the_references_policy_test(name):
+    """8(f) row 3: post_train.policy_test of the REFERENCE (post_train.py:38-128), run in the
+    build container on the reference env (oracle/gen_golden_post_train.py; env_train=False as
+    train/policy_test.py:46 builds it, and the trainer's env_train=True test_env), against
+    rvo3d_amd.policy.post_train with E = 1 on the same action table: every episode's length and
+    mean speed, the success rate and the rounded statistics of the result line."""
     from rvo3d_amd.policy import post_train
-    E, N, nm, T = 6, 8, 10, 400
-    world = synthetic_world(E, N, (12.0, 12.0, 6.0), seed=5)
-    acts = [torch.from_numpy(synthetic_actions(E, N, t, 321).astype(np.float32)).cuda() for t in range(T)]
-
-    class Scripted:
-        def __init__(self): self.t = 0
-        def eval(self): return self
-        def step_tensors(self, obs, std_factor=1):
-            a = acts[self.t].view(-1, 3); self.t += 1
-            return a, None, None
-
-    env = BatchedDroneEnv(world, neighbors_num=nm, action_decimals=-1)
-    pt = post_train(env, num_episodes=14, max_ep_len=25, acceler_vel=1.0, inf_print=False)
-    got = pt.policy_test(policy=Scripted())
+    fx = load(os.path.join(_ROOT, "tests", "golden", name))
+    env = BatchedDroneEnv(world_of(fx), neighbors_num=10, env_train=bool(fx["env_train"]))
+    pt = post_train(env, num_episodes=int(fx["num_episodes"]), max_ep_len=int(fx["max_ep_len"]),
+                    acceler_vel=1.0, inf_print=False, std_factor=1e-5)
+    got = pt.policy_test(policy=_TablePolicy(fx["table"], [0]), policy_name="scripted")
     env.close()
+    arrived = fx["ep_arrived"].astype(bool)
+    assert got["episodes"] == int(fx["num_episodes"]) == len(fx["ep_len"])
+    assert got["ep_len"] == fx["ep_len"][arrived].tolist()
+    np.testing.assert_allclose(got["speed"], fx["ep_speed"], rtol=1e-12)
+    assert got["success_rate"] == pytest.approx(float(fx["success_rate"]), abs=1e-4)  # printed as xx.xx%
+    assert got["success_rate"] == fx["ep_finished"].mean()
+    for k in ("mean_len", "std_len", "average_speed", "std_speed"):
+        assert got[k] == float(fx[k]), k
 
-    ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, nm=nm, threads=8)
-    ref.reset(); ref.observe()
-    ep_len = np.zeros(E, np.int64); speed_sum = np.zeros(E); n = sn = 0
-    lens, speeds = [], []
-    t = 0
-    while n < 14:
-        a_inc = np.round(acts[t].cpu().numpy(), 2); t += 1             # float32
-        action = (np.float32(1.0) * a_inc).astype(np.float64) + ref.get_state()["vel"]
-        ro, rcnt, rr, rd, ri, rf = ref.step(action)
-        speed_sum += np.linalg.norm(ref.get_state()["vel"], axis=-1).mean(axis=1)
-        ep_len += 1
-        ended = rd.astype(bool).any(axis=1) | (ep_len == 25) | rf.astype(bool).all(axis=1)
-        for e in np.nonzero(ended)[0]:
-            if n >= 14:
-                break
-            if ri[e].astype(bool).all():
-                lens.append(int(ep_len[e]))
-            speeds.append(speed_sum[e] / ep_len[e]); n += 1
-            sn += int(rf[e].astype(bool).all())
-        if ended.any():
-            ref.reset(ended.astype(np.uint8)); ref.observe()
-            ep_len[ended] = 0; speed_sum[ended] = 0
-    assert got["episodes"] == 14
-    assert got["success_rate"] == sn / 14
-    assert got["ep_len"] == lens
-    np.testing.assert_allclose(got["speed"], speeds, rtol=1e-12)
-    assert got["average_speed"] == float(np.round(np.mean(speeds), 2))
+
+def test_post_train_batched_envs_contribute_equal_shares():
+    """E > 1: every env contributes its first ceil(num_episodes / E) episodes, whenever they end
+    (NOT "the first num_episodes episodes to end", which would favour collisions).  Env e replays
+    the reference's action table from the start of the reference's episode e, so its episodes are
+    the reference's episodes e, e + 1, ...; the pooled statistics must be those of exactly these."""
+    from rvo3d_amd.policy import post_train
+    fx = load(os.path.join(_ROOT, "tests", "golden", "post_train_world_4_eval.npz"))
+    E, quota = 3, 2
+    starts = np.concatenate([[0], np.cumsum(fx["ep_len"])])[:E].tolist()
+    env = BatchedDroneEnv(world_of(fx, E), neighbors_num=10, env_train=False)
+    pt = post_train(env, num_episodes=E * quota - 1, max_ep_len=int(fx["max_ep_len"]), acceler_vel=1.0,
+                    inf_print=False)
+    got = pt.policy_test(policy=_TablePolicy(fx["table"], starts))
+    env.close()
+    want = [e + k for e in range(E) for k in range(quota)]      # reference episode indices counted
+    assert got["episodes"] == E * quota
+    assert sorted(got["speed"]) == pytest.approx(sorted(fx["ep_speed"][want].tolist()), rel=1e-12)
+    assert sorted(got["ep_len"]) == sorted(fx["ep_len"][want][fx["ep_arrived"][want].astype(bool)].tolist())
+    assert got["success_rate"] == fx["ep_finished"][want].mean()
+    # the short (collision) episodes are not over-represented: lengths 5 appear as often as in `want`
+    assert (fx["ep_len"][want] == 5).sum() == 2
 
 
 @pytest.mark.parametrize("E,N,nb,size", [(4096, 64, 0, (50.0, 50.0, 10.0)),
