@@ -11,15 +11,27 @@ whole batch, with the actions already resident in HBM.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \\
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
-Envs are independent, so N GPUs = N shards of 4096 envs each (weak scaling) and
-no data-path collective; the only collectives are the timing barrier and the
-max-over-ranks of the elapsed time.
+Envs are independent, so N GPUs = N shards of 4096 envs each (weak scaling) and the
+step itself needs no data-path collective.  The one collective of the north-star
+design - the RCCL all-reduce of the flattened policy-gradient bucket plus the mean of
+the KL estimate, once per optimizer step (rvo3d_amd.policy.multi_ppo._allreduce_grads /
+update) - is put INSIDE every timed step whenever N > 1 (or with
+--grad-allreduce): the trainer's own code path on the gradients of the MLP(256,256)
+policy of BASELINE config 3 (0.74 MB fp32).  That is the worst case - one optimizer
+step per env step; training does one per several hundred - so the multi-GPU record
+contains real xGMI traffic and the scaling efficiency read from it is a lower bound.
+At N = 1 the step is the env step alone (the headline).
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : algorithmic bytes per launch / average kernel time (HIP events on
-                 the launch stream) against the 8 TB/s HBM peak
+                 the launch stream) against the 8 TB/s HBM peak; `traffic` (HBM bytes per
+                 launch) and `fp64_valu_tflops` come from the PMC record of this very
+                 command (profiles/traffic.json, written by tools/pmc_record.sh: separate
+                 rocprofv3 --pmc passes) - `traffic_source` says so
   cpu_baseline : the CPU oracle (oracle/, the validated C restatement of the
-                 reference step) timed on this host on a bounded sample.
+                 reference step) timed on this host on a bounded sample, on 1 thread
+                 and on every core the process may use
+  collective   : (N > 1) ranks_seen, allreduce_us, bucket bytes.
 """
 from __future__ import annotations
 
@@ -45,35 +57,66 @@ def algorithmic_bytes_per_drone_step(nm: int, nb: int, N: int) -> float:
 
 
 def cpu_baseline(N, nm, map_size, seconds_target=12.0):
-    """The oracle (kind 'port') on this host: E scaled down, same generator."""
+    """The oracle (kind 'port') on this host, same generator, E scaled down: one thread (the
+    scalar port) and every core this process may run on (OpenMP over envs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc  # test infrastructure, used here only as the timed CPU baseline
     from rvo3d_amd import synthetic_actions, synthetic_world
-    E = 64
-    w = synthetic_world(E, N, map_size)
-    best = None
     ncpu = len(os.sched_getaffinity(0))
-    for threads in sorted({1, min(ncpu, 16)}):
+    recs = {}
+    # 1 thread, the GPU box's per-GPU CPU share (16) and every cpu the process may run on: on a
+    # shared host the last can be slower than the share (oversubscription); the best is reported
+    for threads in sorted({1, min(ncpu, 16), ncpu}):
+        E = 64 if threads == 1 else max(64, 4 * threads)  # several envs per thread
+        w = synthetic_world(E, N, map_size)
         env = orc.OracleEnv(w.waypoints, w.n_points, w.map_size, w.buildings, nm=nm, threads=threads)
         acts = [synthetic_actions(E, N, t) for t in range(8)]
         for t in range(3):
             env.step_autoreset(acts[t])
         t0 = time.perf_counter()
         steps = 0
-        while time.perf_counter() - t0 < seconds_target / 2:
+        while time.perf_counter() - t0 < seconds_target / 3:
             env.step_autoreset(acts[steps % len(acts)])
             steps += 1
         dt = time.perf_counter() - t0
-        rate = E * N * steps / dt
-        rec = dict(value=rate, cores=threads, steps=steps)
-        if threads == 1:
-            one = rate
-        if best is None or rate > best["value"]:
-            best = rec
+        recs[threads] = dict(value=E * N * steps / dt, cores=threads, steps=steps, envs=E)
+    best = max(recs.values(), key=lambda r: r["value"])
+    one = recs[1]
     return {"value": round(best["value"], 1), "unit": "drone-steps/s", "cores": best["cores"],
-            "kind": "port",
-            "sample": f"{N} drones x {E} envs x {best['steps']} fused steps (oracle/rvo3d_oracle.c, "
-                      f"OpenMP over envs; single-thread rate {one:.0f}/s; host has {ncpu} cpus)"}
+            "kind": "port", "value_1core": round(one["value"], 1), "nproc": ncpu,
+            "by_threads": {str(k): round(v["value"], 1) for k, v in sorted(recs.items())},
+            "sample": f"{N} drones x {best['envs']} envs x {best['steps']} fused steps on {best['cores']} threads "
+                      f"(oracle/rvo3d_oracle.c, OpenMP over envs); 1 thread: {N} drones x {one['envs']} envs x "
+                      f"{one['steps']} steps = {one['value']:.0f}/s; this process may use {ncpu} cpus"}
+
+
+class GradBucket:
+    """The policy-gradient collective of one optimizer step, through the trainer's own code
+    (multi_ppo._allreduce_grads + the KL mean of multi_ppo.update): MLP(256,256) actor-critic of
+    BASELINE config 3 on the 12 + 9*nm observation, gradients filled once (their values do not
+    matter to the collective's cost)."""
+
+    def __init__(self, env, dist):
+        from rvo3d_amd.policy import mlp_ac, multi_ppo
+        self.dist = dist
+        self.ac = mlp_ac(env.W).to(env.device)
+        self.tr = multi_ppo(env, self.ac, steps_per_epoch=1, dist=dist)
+        for p in self.ac.parameters():
+            p.grad = torch.ones_like(p)
+        self.kl = torch.zeros(1, dtype=torch.float64, device=env.device)
+        self.ones = torch.ones(1, dtype=torch.float64, device=env.device)
+        self.nbytes = sum(p.numel() for p in self.ac.parameters()) * 4
+
+    def step(self):
+        self.tr._allreduce_grads()              # ONE flattened bucket, sum then / world
+        if self.dist is not None:
+            self.dist.all_reduce(self.kl)       # the KL mean (kept on the device: no host sync here)
+
+    def ranks_seen(self):
+        t = self.ones.clone()
+        if self.dist is not None:
+            self.dist.all_reduce(t)
+        return int(round(float(t.item())))
 
 
 def main():
@@ -91,6 +134,10 @@ def main():
     ap.add_argument("--map", type=float, nargs=3, default=[50.0, 50.0, 10.0])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autoreset", action="store_true")
+    ap.add_argument("--grad-allreduce", action="store_true",
+                    help="every timed step also runs the trainer's gradient-bucket all-reduce + KL mean "
+                         "(default whenever --gpus > 1)")
+    ap.add_argument("--no-grad-allreduce", action="store_true", help="N > 1 without the collective")
     args = ap.parse_args()
 
     from rvo3d_amd import BatchedDroneEnv, _lib, sharding, synthetic_actions, synthetic_world
@@ -122,7 +169,14 @@ def main():
                         for t in range(n_act)]).to(dev)
     autoreset = not args.no_autoreset
     env.observe()
+    with_coll = (world > 1 or args.grad_allreduce) and not args.no_grad_allreduce
+    bucket = GradBucket(env, dist) if with_coll else None
     torch.cuda.synchronize()
+
+    def one_step(t):
+        env.step(acts[t % n_act], autoreset=autoreset)
+        if bucket is not None:
+            bucket.step()
 
     def barrier():
         if dist is not None:
@@ -130,13 +184,13 @@ def main():
         torch.cuda.synchronize()
 
     for t in range(args.prewarm):
-        env.step(acts[t % n_act], autoreset=autoreset)
+        one_step(t)
     for t in range(W):
-        env.step(acts[t % n_act], autoreset=autoreset)
+        one_step(t)
     barrier()
     t0 = time.perf_counter()
     for t in range(K):
-        env.step(acts[(W + t) % n_act], autoreset=autoreset)
+        one_step(W + t)
     barrier()
     elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
 
@@ -151,6 +205,18 @@ def main():
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     flags = env.error_flags()
+    coll = None
+    if bucket is not None:  # the collective alone, same stream, K repetitions
+        ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for a, b in ce:
+            a.record(stream)
+            bucket.step()
+            b.record(stream)
+        torch.cuda.synchronize()
+        coll = dict(ranks_seen=bucket.ranks_seen(), backend="nccl (RCCL)" if world > 1 else "none (1 rank)",
+                    allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
+                    bucket_bytes=bucket.nbytes, per_step="gradient bucket all-reduce + KL mean all-reduce "
+                    "(multi_ppo._allreduce_grads / update), once per timed env step")
 
     if rank == 0:
         total_units = world * E * N * K
@@ -158,11 +224,17 @@ def main():
         B = algorithmic_bytes_per_drone_step(nm, nb, N)
         bytes_per_launch = E * N * B
         achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = fp64_flops = None
+        traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        key = f"{N}x{E}" + (f"+{nb}b" if nb else "")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{N}x{E}")
+                rec = json.load(open(tpath)).get(key)
+                if isinstance(rec, dict):
+                    traffic, fp64_flops = rec.get("hbm_bytes"), rec.get("fp64_flops")
+                    traffic_source = ("profiles/traffic.json[%s]: builder's rocprofv3 --pmc passes of this "
+                                      "command (%s), not measured in this run" % (key, rec.get("source", "tools/pmc_record.sh")))
             except Exception:
                 traffic = None
         out = {
@@ -178,13 +250,21 @@ def main():
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "kernel": ("rvo3d::env_kernel<2, 1, 64> (fused step + auto-reset)" if N == 64 else
-                                    "rvo3d::env_kernel<2, 1> (fused step + auto-reset)") if N <= 64 else
-                                   "rvo3d::env_kernel<2, NW> (fused step + auto-reset)",
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "fp64_valu_tflops": (round(fp64_flops / (kern_ms * 1e-3) / 1e12, 3)
+                                              if fp64_flops else None),
+                         "fp64_valu_peak_tflops": 78.6,
+                         "kernel": "rvo3d::env_kernel<%d, %d, %d, true> (fused step%s)" % (
+                             2 if autoreset else 1, 1 if N <= 64 else 2 if N <= 128 else 4 if N <= 256 else 8,
+                             N if N in (16, 32, 64, 128, 256) and env.launch_info()["envs_per_block"] == max(64 // N, 1) else 0,
+                             " + auto-reset" if autoreset else ""),
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_drone_step": B},
         }
+        if coll is not None:
+            out["collective"] = coll
+            out["config"]["workload"] += "; + gradient-bucket all-reduce and KL mean per step"
         if not args.no_cpu_baseline and world == 1:  # reported once, at N = 1
             out["cpu_baseline"] = cpu_baseline(N, nm, tuple(args.map))
         print(json.dumps(out), flush=True)

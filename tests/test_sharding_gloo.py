@@ -51,6 +51,46 @@ def test_two_rank_gloo_sharding():
     assert s0 != s1                            # different shards = different worlds
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist = sharding.init_process_group("gloo")
+    import bench  # the driver's script: its multi-GPU leg is this class
+
+    class Env:
+        E, N, W, device = 2, 3, 102, torch.device("cpu")
+    b = bench.GradBucket(Env(), dist)
+    for p in b.ac.parameters():
+        p.grad = torch.full_like(p, float(rank + 1))   # rank 0: 1, rank 1: 2 -> mean 1.5
+    b.kl += rank
+    b.step()
+    seen = b.ranks_seen()
+    g = torch.cat([p.grad.reshape(-1) for p in b.ac.parameters()])
+    q.put((rank, seen, float(g.min()), float(g.max()), float(b.kl), b.nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_gradient_bucket_collective_two_ranks():
+    """bench.py's N > 1 leg on CPU (gloo, world_size 2): the trainer's flattened gradient bucket
+    is averaged over the ranks, the KL scalar summed, and ranks_seen comes from a real
+    all-reduce.  0.74 MB = the MLP(256,256) policy of BASELINE config 3."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = sorted(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, gmin, gmax, kl, nbytes in out:
+        assert seen == 2 and gmin == gmax == 1.5 and kl == 1.0
+        assert 0.70e6 < nbytes < 0.80e6
+
+
 def test_shard_ranges_cover_and_are_disjoint():
     for total in (1, 7, 4096, 32768):
         for world in (1, 2, 3, 8):
