@@ -347,6 +347,16 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
     rad[g] = radius ? radius[g] : 0.2;
     pri[g] = priority ? priority[g] : 5.0;
   }
+  {
+    // one radius and one priority for every drone (bit-identical doubles): the step takes them from
+    // its argument block instead of reading 16 B per drone-step
+    bool uni = true;
+    for (size_t g = 1; g < EN && uni; ++g)
+      uni = std::memcmp(&rad[g], &rad[0], 8) == 0 && std::memcmp(&pri[g], &pri[0], 8) == 0;
+    h->P.uniform_rp = uni ? 1 : 0;
+    h->P.r0 = rad[0];
+    h->P.prio0 = pri[0];
+  }
   for (int k = 0; k < P.P; ++k) p95[k] = std::pow(0.95, (double)k);  // ir_gym.py:283
   // [P][3] rows of EN doubles into arrays of stride S
   HIP_TRY(hipMemcpy2DAsync((void*)P.wp(0, 0), (size_t)P.S * 8, wp.data(), EN * 8, EN * 8,

@@ -56,6 +56,8 @@ struct Params {
   int ablate;         // diagnostics build only (tools/): bit k skips phase k, results invalid
 #endif
   int zf16;           // per call: obs is 16-B aligned and W is even -> 16-B zero-fill
+  int uniform_rp;     // 1: every drone has radius r0 and priority prio0 (the reference's constants,
+  double r0, prio0;   //    drone.py:14-15): the step does not read the two arrays (16 B per drone-step)
   double T10;         // max{x : sqrt(x) <= 10}  (rvo_inter.py:96)
   // fp32 candidate filter (stage G): error bands
   float t10n;      // -nextafter(T10 + band): stage G's fma chain starts here, in range iff it ends < 0

@@ -407,7 +407,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   if (active) {
     S.x = P.px()[g]; S.y = P.py()[g]; S.z = P.pz()[g];
     S.vx = P.vx()[g]; S.vy = P.vy()[g]; S.vz = P.vz()[g];
-    S.r = P.radius()[g]; S.prio = P.prio()[g];
+    if (P.uniform_rp) { S.r = P.r0; S.prio = P.prio0; }
+    else { S.r = P.radius()[g]; S.prio = P.prio()[g]; }
     if (MODE != kObserve) {
       if (P.action_mode == 1) {
         // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:

@@ -190,14 +190,14 @@ def test_hip_replays_reference_golden(path):
 
 
 def run_vs_oracle(world, T, nm=10, autoreset=True, f32_actions=False, radius=None, seed=1234,
-                  vlike=False, env_train=True, name=None):
+                  vlike=False, env_train=True, name=None, priority=None):
     E, N, _ = world.shape
     dec = 2 if f32_actions else -1
     env = BatchedDroneEnv(world, neighbors_num=nm, action_decimals=dec, radius=radius,
-                          env_train=env_train)
+                          env_train=env_train, priority=priority)
+    bc = lambda x: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (E, N)))
     ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, nm=nm,
-                        radius=None if radius is None else np.full((E, N), radius), threads=8,
-                        env_train=env_train)
+                        radius=bc(radius), priority=bc(priority), threads=8, env_train=env_train)
     o0, c0 = env.observe()
     r0, rc0 = ref.observe()
     tl = Tally(name or f"oracle/{N}x{E}_nm{nm}_T{T}_seed{seed}", E)
@@ -348,6 +348,24 @@ def test_dense_small_nm_truncation():
     st = run_vs_oracle(synthetic_world(64, 32, (12, 12, 5), min_sep=0.8), T=40, nm=2, radius=0.3,
                        vlike=True, autoreset=False)
     assert st["vo_rows"] > 500, st
+
+
+@pytest.mark.parametrize("N,E", [(16, 64), (64, 12), (100, 3)])
+def test_per_drone_radius_and_priority(N, E):
+    """radius / priority arrays that differ from drone to drone (the step then reads them per
+    drone instead of taking the one value from its argument block; get_PAA's pr = pra / (pra + prb)
+    is no longer 0.5, vel_obs3D.py:19-32; the fp32 cone filter stands down for unequal priorities)."""
+    rng = np.random.default_rng(8)
+    L = 6 + 2.5 * np.sqrt(N)
+    world = synthetic_world(E, N, (L, L, 6.0), min_sep=1.3, seed=23)
+    radius = np.round(rng.uniform(0.15, 0.5, (E, N)), 2)
+    priority = rng.integers(1, 9, (E, N)).astype(np.float64)
+    st = run_vs_oracle(world, T=30, autoreset=False, radius=radius, priority=priority, vlike=True,
+                       name=f"per_drone_rp/{N}x{E}")
+    assert st["vo_rows"] > 20 and st["done"] > 0, st
+    st = run_vs_oracle(world, T=20, autoreset=True, radius=radius, priority=priority, seed=3,
+                       name=f"per_drone_rp/{N}x{E}_autoreset")
+    assert st["resets"] > 0, st
 
 
 def test_cfg2_velocity_like_actions():

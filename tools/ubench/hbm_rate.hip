@@ -11,6 +11,21 @@ __global__ void k_write(v4* dst, size_t n) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += st) dst[i] = (v4){0.f, 0.f, 0.f, 0.f};
 }
+__global__ void k_write_nt(v4* dst, size_t n) {
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) __builtin_nontemporal_store((v4){0.f, 0.f, 0.f, 0.f}, &dst[i]);
+}
+// the step's shape with non-temporal stores
+__global__ void k_mix_nt(const v4* src, v4* dst, int nr, int nw, float* sink) {
+  const size_t wv = blockIdx.x;
+  const v4* s = src + wv * (size_t)nr * 64;
+  v4* d = dst + wv * (size_t)nw * 64;
+  v4 a = {0, 0, 0, 0};
+  for (int i = 0; i < nr; ++i) a += s[(size_t)i * 64 + threadIdx.x];
+  a.x = a.x * 0.f;
+  for (int i = 0; i < nw; ++i) __builtin_nontemporal_store((v4){a.x, 0.f, 0.f, 0.f}, &d[(size_t)i * 64 + threadIdx.x]);
+  if (a.y == 123.456f) sink[0] = a.y;
+}
 __global__ void k_read(const v4* src, size_t n, float* sink) {
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
   v4 a = {0, 0, 0, 0};
@@ -55,6 +70,8 @@ int main() {
     float w = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_write, g, t, 0, 0, B + o, bytesW / 16); }, 50);
     float r = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_read, g, t, 0, 0, A + o, bytesR / 16, sink); }, 50);
     float c = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_copy, g, t, 0, 0, A + o, B + o, (size_t)100 * MB / 16); }, 50);
+    float wn = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_write_nt, g, t, 0, 0, B + o, bytesW / 16); }, 50);
+    printf("grid %d x %d: write 141 MB non-temporal %.1f us (%.2f TB/s)\n", g.x, t.x, wn * 1e3, bytesW / wn / 1e9);
     printf("grid %d x %d: write 141 MB %.1f us (%.2f TB/s) | read 62 MB %.1f us (%.2f TB/s) | copy 100+100 MB %.1f us (%.2f TB/s)\n",
            g.x, t.x, w * 1e3, bytesW / w / 1e9, r * 1e3, bytesR / r / 1e9, c * 1e3, 200.0 * MB / c / 1e9);
   }
@@ -64,6 +81,8 @@ int main() {
     float m = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_mix, dim3(4096), dim3(64), 0, 0, A + o, B + o, nr, nw, sink); }, 50);
     const double by = 4096.0 * 64 * 16 * (nr + nw);
     printf("mix 4096 waves, read %d then write %d chunks per lane: %.1f MB in %.1f us (%.2f TB/s)\n", nr, nw, by / 1e6, m * 1e3, by / m / 1e9);
+    float mn = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_mix_nt, dim3(4096), dim3(64), 0, 0, A + o, B + o, nr, nw, sink); }, 50);
+    printf("  same with non-temporal stores: %.1f us (%.2f TB/s)\n", mn * 1e3, by / mn / 1e9);
   }
   return 0;
 }
