@@ -628,6 +628,43 @@ def test_eval_mode_env_train_false_vs_oracle(N, E, radius):
             assert st["domain_pairs"] > 0, st
 
 
+def test_more_than_2pow24_observation_rows():
+    """E * N = 16.8 M rows (> 2^24): the row writer's index arithmetic is relative to the workgroup,
+    so the rows far into a 6.8 GB observation tensor are written like the first ones (the chunk-indexed
+    writer of round 1 decoded row 16 777 221 as row 5).  One world of 4100 envs tiled 64 times; the
+    envs at the very end of the batch are compared with the oracle, and with the first copy."""
+    E0, reps, N = 4100, 64, 64
+    E = E0 * reps
+    assert E * N > (1 << 24)
+    w0 = synthetic_world(E0, N, (50.0, 50.0, 10.0))
+    world = type(w0)(np.tile(w0.waypoints, (reps, 1, 1, 1)), np.tile(w0.n_points, (reps, 1)), w0.map_size,
+                     w0.buildings)
+    env = BatchedDroneEnv(world, neighbors_num=10, action_decimals=2)
+    pick = np.array([0, 1, E0 - 1, E - E0, E - 2, E - 1])          # first copy and last copy
+    sub = type(w0)(world.waypoints[pick], world.n_points[pick], w0.map_size, w0.buildings)
+    ref = orc.OracleEnv(sub.waypoints, sub.n_points, sub.map_size, sub.buildings, nm=10, threads=6)
+    env.observe(); ref.observe()
+    tl = Tally("rows_beyond_2pow24", len(pick))
+    for t in range(3):
+        a0 = synthetic_actions(E0, N, t).astype(np.float32)
+        a = torch.from_numpy(a0).cuda().repeat(reps, 1, 1)
+        obs, cnt, rew, done, info, fin = env.step(a, autoreset=True)
+        ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(np.tile(a0, (reps, 1, 1))[pick].astype(np.float64))
+        tl.begin(ref.margin())
+        tl.check(f"done t={t}", done[pick].cpu().numpy() == rd)
+        tl.check(f"vo_count t={t}", cnt[pick].cpu().numpy() == rcnt)
+        tl.check(f"obs t={t}", eq_nan(obs[pick].cpu().numpy(), ro.astype(np.float32)))
+        tl.check(f"reward t={t}", eq_nan(rew[pick].cpu().numpy(), rr.astype(np.float32)))
+        tl.end()
+        # every copy of the world behaves like the first (identical inputs): whole-tensor check on the device
+        o = obs.view(reps, E0, N, -1)
+        assert bool(torch.equal(torch.nan_to_num(o[0]), torch.nan_to_num(o[reps - 1])))
+        assert bool(torch.equal(cnt.view(reps, E0, N)[0], cnt.view(reps, E0, N)[reps // 2]))
+    assert env.error_flags() == (1 if ref.nan_count else 0)
+    env.close()
+    tl.finish(rows=E * N)
+
+
 def test_env_checkpoint_resume_is_bit_exact(tmp_path):
     """state_dict -> torch.save -> load (weights_only) -> load_state_dict resumes the rollout
     exactly: every output of the following steps is identical."""
