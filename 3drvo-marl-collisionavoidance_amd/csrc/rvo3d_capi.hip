@@ -505,6 +505,12 @@ int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype
                      reset_mask, true, stream);
 }
 
+int rvo3d_set_reward_f64(rvo3d_env* h, double* reward64) {
+  if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
+  h->P.reward64 = reward64;
+  return RVO3D_OK;
+}
+
 int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
   DeviceGuard dg;
   int rc = check(h, true, dg);

@@ -140,6 +140,7 @@ struct Params {
   float* obs;
   int32_t* vo_count;
   float* reward;
+  double* reward64;   // optional: the same reward as the reference returns it, float64 (mdin.py:28)
   uint8_t *done, *info, *finish, *reset_mask;
 };
 

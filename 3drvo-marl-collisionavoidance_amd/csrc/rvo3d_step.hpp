@@ -355,11 +355,9 @@ __device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, 
   return __builtin_rint((reward + dev_pen + ex_pen) * 1000.0);
 }
 
-// mdin.py:28 adds two np.round(., 3) values in fp64; k / 1000 is formed exactly
-// (k_over_1000) so the sum, cancellation included, is the reference's double.
-__device__ __forceinline__ float reward_f32(double k1, double k2) {
-  return (float)(k_over_1000(k1) + k_over_1000(k2));
-}
+// mdin.py:28 adds two np.round(., 3) values in fp64; k / 1000 is formed exactly (k_over_1000)
+// so the sum, cancellation included, is the reference's double (stored as float32, and as it is
+// into the optional float64 output).
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
@@ -628,7 +626,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   }
   bool do_reset = false;
   if (active) {
-    P.reward[g] = reward_f32(rew_k, collision ? -50000.0 : mov_nc);  // mdin.py:28
+    const double rew64 = k_over_1000(rew_k) + k_over_1000(collision ? -50000.0 : mov_nc);  // mdin.py:28
+    P.reward[g] = (float)rew64;
+    if (P.reward64) P.reward64[g] = rew64;
     P.done[g] = collision ? 1 : 0;
     do_reset = LITE && (collision || f_dest);
   }

@@ -75,7 +75,7 @@ class StateView(C.Structure):
 # every symbol include/rvo3d.h declares (tests check the library exports them all)
 SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
-           "rvo3d_step_policy",
+           "rvo3d_step_policy", "rvo3d_set_reward_f64",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
            "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_version", "rvo3d_last_error")
 
@@ -102,6 +102,7 @@ def lib():
     L.rvo3d_step.argtypes = [vp, vp, i32] + [vp] * 7
     L.rvo3d_step_autoreset.argtypes = [vp, vp, i32] + [vp] * 8
     L.rvo3d_step_policy.argtypes = [vp, vp, C.c_float] + [vp] * 7 + [i32, vp]
+    L.rvo3d_set_reward_f64.argtypes = [vp, vp]
     L.rvo3d_des_vel.argtypes = [vp, vp, vp]
     L.rvo3d_rvo_vel.argtypes = [vp, C.POINTER(C.c_double), C.c_double, vp, vp]
     L.rvo3d_state_ptrs.argtypes = [vp, C.POINTER(StateView)]

@@ -30,7 +30,7 @@ def _ptr(t):
 class BatchedDroneEnv:
     def __init__(self, world: World, neighbors_num: int = 10, env_train: bool = True,
                  device="cuda:0", action_decimals: int = -1, radius=None, priority=None,
-                 acceler: float = 0.5):
+                 acceler: float = 0.5, reward_f64: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("rvo3d_amd needs a GPU: there is no CPU fallback "
                                "(the CPU oracle under oracle/ is test infrastructure only)")
@@ -69,6 +69,11 @@ class BatchedDroneEnv:
         self.info = torch.zeros((E, N), dtype=torch.uint8, device=dev)
         self.finish = torch.zeros((E, N), dtype=torch.uint8, device=dev)
         self.reset_mask = torch.zeros((E, N), dtype=torch.uint8, device=dev)
+        # optional float64 copy of the reward, as the reference returns it (mdin.py:28)
+        self.reward64 = None
+        if reward_f64:
+            self.reward64 = torch.zeros((E, N), dtype=torch.float64, device=dev)
+            _lib.check(L.rvo3d_set_reward_f64(h, _ptr(self.reward64)), "rvo3d_set_reward_f64")
 
     # -- plumbing ---------------------------------------------------------------
     def _stream(self):

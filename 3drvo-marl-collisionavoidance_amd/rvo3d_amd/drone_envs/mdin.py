@@ -116,7 +116,7 @@ class mdin:
             world = world_from_dict(world)
         assert isinstance(world, World) and world.shape[0] == 1, "mdin is the one-env façade"
         self._env = BatchedDroneEnv(world, neighbors_num=neighbors_num, env_train=env_train,
-                                    device=device, acceler=acceler)
+                                    device=device, acceler=acceler, reward_f64=True)
         self.ir_gym = _IrGym(self._env, acceler, neighbors_region, neighbors_num, env_train)
         self.observation_space = self.ir_gym.observation_space
         self.action_space = self.ir_gym.action_space
@@ -137,7 +137,7 @@ class mdin:
         obs_list = g._ragged(obs, cnt)
         if not all(np.isfinite(o).all() for o in obs_list):
             raise ValueError("observation contains NaN/Inf")   # ir_gym.py:232-239
-        return (obs_list, list(rew[0].cpu().numpy().astype(np.float64)),
+        return (obs_list, list(self._env.reward64[0].cpu().numpy()),   # float64, as mdin.py:28 returns it
                 [bool(x) for x in done[0].cpu().numpy()], [bool(x) for x in info[0].cpu().numpy()],
                 [bool(x) for x in fin[0].cpu().numpy()])
 

@@ -140,6 +140,12 @@ int rvo3d_step_policy(rvo3d_env *h, const float *a_inc, float acceler, float *ob
                       int32_t *vo_count, float *reward, uint8_t *done, uint8_t *info,
                       uint8_t *finish, uint8_t *reset_mask, int32_t autoreset, void *stream);
 
+/* mdin.drone_step returns its rewards as Python floats (mdin.py:28: rvo_reward + mov_reward in
+ * float64).  Attach a device buffer reward64 [E][N] and every following step (all three step
+ * entry points) also writes the float64 value next to the float32 one; NULL detaches.  The
+ * buffer is borrowed until detached or the handle is destroyed. */
+int rvo3d_set_reward_f64(rvo3d_env *h, double *reward64);
+
 /* ir_gym.cal_des_list (ir_gym.py:44): desired velocity, des_vel [E][N][3] f64. */
 int rvo3d_des_vel(rvo3d_env *h, double *des_vel, void *stream);
 

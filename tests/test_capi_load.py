@@ -18,7 +18,7 @@ def so():
 
 def test_header_symbols_all_exported(so):
     hdr = open(os.path.join(ROOT, "include", "rvo3d.h")).read()
-    declared = set(re.findall(r"\b(rvo3d_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(rvo3d_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     L = C.CDLL(so)
     for s in declared:
