@@ -173,44 +173,51 @@ class multi_ppo:
         ret_sum = torch.zeros((), device=self.device)
         ret_n = torch.zeros((), device=self.device)
         since_full_reset = 0  # no episode can be longer than this: timeouts need no device check before
+        hundred = torch.full((self.E, self.N, 3), 100.0, dtype=torch.float32, device=self.device)
         with torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp):
             for t in range(self.steps_per_epoch):
                 obs, cnt = buf.obs[t], buf.cnt[t]
                 a, v, logp = self.ac.step_tensors((obs.view(-1, env.W), cnt.view(-1)))
-                a, v, logp = a.float(), v.float(), logp.float()
-                a = a.view(self.E, self.N, 3)
+                a = a.float().view(self.E, self.N, 3)
                 # a_inc = round(a, 2); abs = round(acceler * a_inc + vel, 2); drone_step; resets of
                 # done|finish drones + env_observation: one launch (multi_ppo.py:196-242)
                 _, _, rew, done, info, fin = env.step_policy(a, autoreset=True, obs_out=buf.obs[t + 1],
                                                              cnt_out=buf.cnt[t + 1])
                 # what the reference stores (multi_ppo.py:197): rint(a * 100) / 100 in float32 with a
-                # true division (a scalar divisor would become a multiplication by 1/100)
-                a_inc = torch.round(a * 100.0) / torch.full_like(a, 100.0)
-                if self.sanitize_rewards:
-                    rew = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
-                buf.store(obs, cnt, a_inc, rew, v.view(self.E, self.N), logp.view(self.E, self.N))
-                self.ep_ret += torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+                # true division (a scalar divisor would become a multiplication by 1/100); written
+                # straight into the buffer slot, like everything else of this step
+                torch.div(torch.round(a * 100.0), hundred, out=buf.act[t])
+                rew_fin = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+                buf.rew[t].copy_(rew_fin if self.sanitize_rewards else rew)
+                buf.val[t].copy_(v.view(self.E, self.N))
+                buf.logp[t].copy_(logp.view(self.E, self.N))
+                buf.ptr += 1
+                self.ep_ret += rew_fin
                 self.ep_len += 1
                 since_full_reset += 1
-                finb, doneb = fin.bool(), done.bool()
-                timeout = self.ep_len > self.max_ep_len
                 epoch_ended = t == self.steps_per_epoch - 1
-                terminal = (finb | timeout).any(dim=1)  # any drone of the env (multi_ppo.py:229)
-                ended = doneb | finb | timeout
+                reset_by_step = (done | fin) != 0        # what the fused step already reset
+                if epoch_ended:                          # full reset (multi_ppo.py:244-264)
+                    ended = torch.ones_like(reset_by_step)
+                    terminal = torch.ones(self.E, dtype=torch.bool, device=self.device)
+                    extra = ~reset_by_step
+                elif since_full_reset > self.max_ep_len:  # only now can an episode time out
+                    timeout = self.ep_len > self.max_ep_len
+                    ended = reset_by_step | timeout
+                    terminal = ((fin != 0) | timeout).any(dim=1)  # any drone of the env (multi_ppo.py:229)
+                    extra = timeout & ~reset_by_step
+                else:
+                    ended = reset_by_step
+                    terminal = (fin != 0).any(dim=1)
+                    extra = None
                 ret_sum += (self.ep_ret * ended).sum()
                 ret_n += ended.sum()
-                extra = timeout & ~(doneb | finb)  # not yet reset by the fused step
-                if epoch_ended:
-                    extra = ~(doneb | finb)         # full reset (multi_ppo.py:244-264)
-                    terminal = torch.ones_like(terminal)
-                    ended = torch.ones_like(ended)
-                may_time_out = since_full_reset > self.max_ep_len
-                if epoch_ended or (may_time_out and bool(extra.any())):
+                if epoch_ended or (extra is not None and bool(extra.any())):
                     env.reset_drones(extra)
                     env.observe(obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
                 buf.finish_path(terminal)
-                self.ep_ret = torch.where(ended, torch.zeros_like(self.ep_ret), self.ep_ret)
-                self.ep_len = torch.where(ended, torch.zeros_like(self.ep_len), self.ep_len)
+                self.ep_ret.masked_fill_(ended, 0.0)
+                self.ep_len.masked_fill_(ended, 0)
         self._cur = (buf.obs[self.steps_per_epoch], buf.cnt[self.steps_per_epoch])
         return float(ret_sum / ret_n.clamp(min=1))
 

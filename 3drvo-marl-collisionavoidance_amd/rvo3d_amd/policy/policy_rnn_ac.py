@@ -21,6 +21,24 @@ import torch.nn as nn
 from torch.distributions.normal import Normal
 
 
+_CAST_CACHE = {}
+
+
+def _cast_cached(p, dtype):
+    """p.to(dtype) for inference, computed once per parameter VERSION: the rollout calls the policy
+    hundreds of times between two optimizer steps, and an optimizer step bumps `p._version` (in-place
+    update), which invalidates the entry.  (14 cast kernels per rollout step otherwise.)"""
+    if p.dtype == dtype:
+        return p
+    key = (id(p), dtype)
+    hit = _CAST_CACHE.get(key)
+    if hit is not None and hit[0] == p._version and hit[1].device == p.device:
+        return hit[1]
+    t = p.detach().to(dtype)
+    _CAST_CACHE[key] = (p._version, t)
+    return t
+
+
 def mlp(sizes, activation, output_activation=nn.Identity):  # policy_rnn_ac.py:10-17
     layers = []
     for j in range(len(sizes) - 1):
@@ -260,8 +278,8 @@ class mlp_ac(nn.Module):
         dt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
         h = x.to(dt)
         for m in lin[:-1]:
-            h = torch._addmm_activation(m.bias.to(dt), h, m.weight.to(dt).t(), use_gelu=False)
-        h = torch.nn.functional.linear(h, lin[-1].weight.to(dt), lin[-1].bias.to(dt))
+            h = torch._addmm_activation(_cast_cached(m.bias, dt), h, _cast_cached(m.weight, dt).t(), use_gelu=False)
+        h = torch.nn.functional.linear(h, _cast_cached(lin[-1].weight, dt), _cast_cached(lin[-1].bias, dt))
         return acts[-1](h)
 
     def step_tensors(self, obs, std_factor=1):
