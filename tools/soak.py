@@ -23,6 +23,13 @@ cases = [
     dict(E=64, N=32, size=(12, 12, 5), T=40, kw=dict(autoreset=False, vlike=True, nm=2, radius=0.3), min_sep=0.8),
     dict(E=48, N=48, size=(14, 14, 5), T=40, kw=dict(autoreset=True, vlike=True, nm=10, radius=0.3), min_sep=0.8),
     dict(E=32, N=64, size=(16, 16, 5), T=40, kw=dict(autoreset=False, vlike=True, nm=4, radius=0.25), min_sep=0.7),
+    # round 2: the compile-time-N kernels at 128 / 256 drones, env_train=False, 96 drones (generic kernel)
+    dict(E=12, N=256, size=(100, 100, 10), T=40, kw=dict(autoreset=True), nb=50),
+    dict(E=12, N=256, size=(60, 60, 10), T=30, kw=dict(autoreset=False, vlike=True, nm=6)),
+    dict(E=24, N=128, size=(50, 50, 10), T=50, kw=dict(autoreset=True, vlike=True)),
+    dict(E=24, N=96, size=(40, 40, 8), T=50, kw=dict(autoreset=True, nm=10), nb=8),
+    dict(E=64, N=32, size=(20, 20, 6), T=60, kw=dict(autoreset=True, env_train=False, radius=0.4), min_sep=1.2),
+    dict(E=32, N=64, size=(30, 30, 8), T=60, kw=dict(autoreset=False, env_train=False, vlike=True, radius=0.3), min_sep=1.0),
 ]
 base = int(os.environ.get("SOAK_SEED", "0"))
 for i, c in enumerate(cases):
