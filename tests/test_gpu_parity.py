@@ -375,6 +375,47 @@ def test_cfg2_velocity_like_actions():
     assert st["vo_rows"] > 50, st
 
 
+@pytest.mark.parametrize("N,E", [(16, 12), (100, 3)])
+def test_drones_far_outside_the_map_bypass_the_fp32_filters(N, E):
+    """The fp32 stages (G, X1) assume centred coordinates within `cmax` of the map; an env with a
+    drone beyond that (here: clusters teleported hundreds of metres away, close enough to each
+    other to interact) switches to the exact path for every pair.  Results must not change."""
+    world = synthetic_world(E, N, (20.0, 20.0, 8.0), seed=31)
+    env = BatchedDroneEnv(world, neighbors_num=10, action_decimals=-1)
+    ref = orc.OracleEnv(world.waypoints, world.n_points, world.map_size, world.buildings, nm=10, threads=8)
+    env.observe(); ref.observe()
+    rng = np.random.default_rng(2)
+    tl = Tally(f"far_bypass/{N}x{E}", E)
+    rows = 0
+    for t in range(12):
+        if t % 3 == 0:  # every third step: half of the envs get a far-away cluster
+            st = ref.get_state()
+            pos, vel = st["pos"].copy(), st["vel"].copy()
+            for e in range(0, E, 2):
+                k = max(N // 3, 2)
+                centre = np.array([400.0 + 50 * e, -300.0, 4.0])
+                pos[e, :k] = np.round(centre + rng.uniform(-2.0, 2.0, (k, 3)), 2)
+                vel[e, :k] = np.round(rng.normal(0, 0.6, (k, 3)), 2)
+            env.set_state(pos=pos, vel=vel); ref.set_state(pos=pos, vel=vel)
+        a = np.round(ref.get_state()["vel"] + synthetic_actions(E, N, t, 5), 2)
+        auto = t % 2 == 1
+        obs, cnt, rew, done, info, fin = env.step(torch.from_numpy(a).cuda(), autoreset=auto)
+        if auto:
+            ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(a)
+        else:
+            ro, rcnt, rr, rd, ri, rf = ref.step(a)
+        tl.begin(ref.margin())
+        tl.check(f"done t={t}", done.cpu().numpy() == rd)
+        tl.check(f"vo_count t={t}", cnt.cpu().numpy() == rcnt)
+        tl.check(f"obs t={t}", eq_nan(obs.cpu().numpy(), ro.astype(np.float32)))
+        tl.check(f"reward t={t}", eq_nan(rew.cpu().numpy(), rr.astype(np.float32)))
+        tl.end()
+        rows += int(rcnt.sum())
+    assert rows > 0
+    env.close()
+    tl.finish(vo_rows=rows)
+
+
 def test_empty_neighbourhood_single_drone():
     st = run_vs_oracle(synthetic_world(9, 1, (10, 10, 5)), T=20)
     assert st["vo_rows"] == 0
