@@ -149,8 +149,16 @@ __device__ __forceinline__ void stage_f32(const Params& P, const Lds& L, int el,
   if (!active) return;
   const double cx = p[0] - P.cold().cen[0], cy = p[1] - P.cold().cen[1], cz = p[2] - P.cold().cen[2];
   const float fvx = (float)v[0], fvy = (float)v[1], fvz = (float)v[2];
+  // kd: fp32 error bound of v.rel ("possibly approaching" is v.rel > -kd, seen from the other
+  // side v.rel < kd).  A drone whose velocity is EXACTLY zero (reset, or speed clamped at 0,
+  // drone.py:452 - common) has v.rel == 0 exactly, which the reference treats as "not
+  // approaching" (rvo_inter.py:159: dot <= 0 returns): kd = -1 makes both tests fail, instead
+  // of sending every in-range pair of two resting drones (w = 0: the cone filter cannot decide)
+  // to the exact stage - 0.59 of the 0.60 requests per lane of the rows sweep were these.
+  const bool vzero = v[0] == 0.0 && v[1] == 0.0 && v[2] == 0.0;
   const float val[12] = {(float)cx, (float)cy, (float)cz, fvx, fvy, fvz, (float)r,
-                         P.cold().kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
+                         vzero ? -1.0f
+                               : P.cold().kdot * (__builtin_fabsf(fvx) + __builtin_fabsf(fvy) + __builtin_fabsf(fvz)) + 1e-30f,
                          (float)az[0], (float)az[1], (float)az[2], (float)prio};
   const int o = el * 2 * P.N + d, os = el * P.N + d;
 #pragma unroll
@@ -388,6 +396,14 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
   if (ROWS && !TOUCH) RVO3D_STAMP(12);
   if (!ROWS) RVO3D_STAMP(14);
   __syncthreads();
+#ifdef RVO3D_DIAG
+  if (P.dbg && active) {  // diagnostics build: X2 requests of this workgroup (sum, max per lane)
+    int c = 0;
+    for (int w = 0; w < NW; ++w) c += __builtin_popcountll(L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull));
+    atomicAdd(&P.dbg[(size_t)blockIdx.x * 24 + (ROWS ? 22 : 20)], (unsigned long long)c);
+    atomicMax(&P.dbg[(size_t)blockIdx.x * 24 + (ROWS ? 23 : 21)], (unsigned long long)c);
+  }
+#endif
   if (active && !RVO3D_ABLATED(32)) {
     const int lbase = el * N;
 #pragma unroll

@@ -32,6 +32,11 @@ if s[:, 16:20].any():
           f"{(s[:, 19] - s[:, 18]).mean():8.0f}  buildings + map + stores + restage {(s[:, 4] - s[:, 19]).mean():8.0f}")
     print(f"  rows phase: kept VO rows {(s[:, 16] - s[:, 7]).mean():8.0f}  stage_row + barrier {(s[:, 17] - s[:, 16]).mean():8.0f}  "
           f"row fill {(s[:, 8] - s[:, 17]).mean():8.0f}")
+if s[:, 20:24].any():
+    T_ = env.launch_info()["threads"]
+    print(f"  X2 requests per lane: sweep A mean {s[:, 20].mean() / T_:.4f} (max lane of a workgroup: mean {s[:, 21].mean():.2f}, "
+          f"workgroups with none {100 * (s[:, 21] == 0).mean():.1f} %)  rows sweep mean {s[:, 22].mean() / T_:.4f} "
+          f"(max lane mean {s[:, 23].mean():.2f}, none {100 * (s[:, 23] == 0).mean():.1f} %)")
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
 
