@@ -302,6 +302,13 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
                             : (cand_t)((unsigned long long)gw[CW * w] |
                                        ((unsigned long long)gw[CW * w + (CW - 1)] << 32));
       if (RVO3D_ABLATED(64)) cand = 0;
+#ifdef RVO3D_DIAG
+      if (P.dbg && ROWS) {  // diagnostics build: X1 candidates of this workgroup in the rows sweep (sum, max per lane)
+        const int c = CW == 1 ? __builtin_popcount((uint32_t)cand) : __builtin_popcountll(cand);
+        atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + 24], (unsigned long long)c);
+        atomicMax(&P.dbg[(size_t)blockIdx.x * 32 + 25], (unsigned long long)c);
+      }
+#endif
       while (cand) {
         const int kb0 = CW == 1 ? __builtin_ctz((uint32_t)cand) : __builtin_ctzll(cand);
         cand &= cand - 1;
@@ -400,8 +407,8 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
   if (P.dbg && active) {  // diagnostics build: X2 requests of this workgroup (sum, max per lane)
     int c = 0;
     for (int w = 0; w < NW; ++w) c += __builtin_popcountll(L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull));
-    atomicAdd(&P.dbg[(size_t)blockIdx.x * 24 + (ROWS ? 22 : 20)], (unsigned long long)c);
-    atomicMax(&P.dbg[(size_t)blockIdx.x * 24 + (ROWS ? 23 : 21)], (unsigned long long)c);
+    atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + (ROWS ? 22 : 20)], (unsigned long long)c);
+    atomicMax(&P.dbg[(size_t)blockIdx.x * 32 + (ROWS ? 23 : 21)], (unsigned long long)c);
   }
 #endif
   if (active && !RVO3D_ABLATED(32)) {

@@ -133,7 +133,7 @@ struct Params {
   const Cold* cold_;   // device copy of the rarely used parameters
   __device__ __forceinline__ ColdC& cold() const { return *(ColdC*)cold_; }
 #ifdef RVO3D_DIAG
-  unsigned long long* dbg;  // diagnostics build only: per-workgroup s_memtime stamps [blocks][24], or null
+  unsigned long long* dbg;  // diagnostics build only: per-workgroup s_memtime stamps [blocks][32], or null
 #endif
   // per-call I/O
   const void* actions;
@@ -151,7 +151,7 @@ struct Params {
 #ifdef RVO3D_DIAG
 #define RVO3D_STAMP(i)                                                                  \
   do {                                                                                  \
-    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 24 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (P.dbg && threadIdx.x == 0) P.dbg[(size_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define RVO3D_ABLATED(bits) ((P.ablate & (bits)) != 0)
 #else

@@ -16,7 +16,7 @@ env.observe()
 for t in range(10):
     env.step(acts[t], autoreset=True)
 nb = env.launch_info()["blocks"]
-buf = torch.zeros((nb, 24), dtype=torch.int64, device="cuda")
+buf = torch.zeros((nb, 32), dtype=torch.int64, device="cuda")
 _lib.check(_lib.lib().rvo3d_debug_stamps(env._h, C.c_void_p(buf.data_ptr())), "stamps")
 env.step(acts[10], autoreset=True)
 torch.cuda.synchronize()
@@ -37,6 +37,10 @@ if s[:, 20:24].any():
     print(f"  X2 requests per lane: sweep A mean {s[:, 20].mean() / T_:.4f} (max lane of a workgroup: mean {s[:, 21].mean():.2f}, "
           f"workgroups with none {100 * (s[:, 21] == 0).mean():.1f} %)  rows sweep mean {s[:, 22].mean() / T_:.4f} "
           f"(max lane mean {s[:, 23].mean():.2f}, none {100 * (s[:, 23] == 0).mean():.1f} %)")
+if s[:, 24:26].any():
+    T_ = env.launch_info()["threads"]
+    print(f"  X1 candidates per lane in the rows sweep: mean {s[:, 24].mean() / T_:.3f}; busiest lane of a workgroup: mean {s[:, 25].mean():.2f} "
+          f"p95 {np.percentile(s[:, 25], 95):.0f} (trips = half of it)")
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
 
