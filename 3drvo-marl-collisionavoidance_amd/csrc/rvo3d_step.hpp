@@ -169,10 +169,7 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * nwv;
         const int lr0 = rbase + 2 * i + s0, lr1 = rbase + 2 * i + s1;
-        bool live = lane_on & (i < npairs);
-#ifdef RVO3D_DIAG
-        if (RVO3D_ABLATED(128)) live &= (p0 | p1);
-#endif
+        const bool live = lane_on & (i < npairs);
         const bool v0 = live & ((unsigned)lr0 < (unsigned)nrows) & (p0 | (u0 >= z0[u]));
         const bool v1 = live & ((unsigned)lr1 < (unsigned)nrows) & (p1 | (u1 >= z1[u]));
         const float2 a = p0 ? d0[u] : make_float2(0.f, 0.f);
@@ -186,29 +183,75 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
   }
 }
 
-#ifdef RVO3D_DIAG
-// EXPERIMENT (diagnostics build, RVO3D_ABLATE bit 128; results invalid for rows with kept VO
-// rows): zeros of every chunk that lies wholly inside a VO region, issued before the final sweep.
+// ---- two-phase row writer (fused auto-reset step; workgroup rows a multiple of 8, W even, >= 48) --
+// The workgroup's rows are then a byte range that starts and ends on 64-B boundaries.  Seen in 64-B
+// blocks, a block either holds proprio bytes of some row ("late": 2 of every ~6.4) or only
+// VO-region bytes ("early").  The early blocks need no data at all: their zeros are stored BEFORE
+// the rows sweep - 69 % of the observation bytes leave while the sweep computes instead of in the
+// store burst at the end of the kernel - and a lane whose sweep then keeps VO rows writes them over
+// the zeros afterwards (after s_waitcnt vmcnt(0): the zeros of its own wave have landed; workgroups
+// of several waves drain before the sweep's second barrier).  The late blocks are written after the
+// sweep as 128-B windows, one per row, from the proprio staged in LDS (part 2 below).
+__device__ __forceinline__ bool two_phase_rows(const Params& P, int row0, int nrows) {
+  return P.zf16 && P.W >= 48 && ((row0 | nrows) & 7) == 0;
+}
+
+// part 1: zeros of every 64-B block that holds no proprio byte.  One wave-instruction = 16 blocks
+// (1 KB, whole lines); the block's offset inside its row advances by a constant per trip.
 template <int NW>
-__device__ __forceinline__ void early_zero_fill(const Params& P, const Lds& L, int tid, int row0, int nrows) {
-  const int q = P.W >> 1;
+__device__ __forceinline__ void early_zero_blocks(const Params& P, const Lds& L, int tid, int row0,
+                                                  int nrows) {
+  const uint32_t rb = 4u * (uint32_t)P.W;  // row bytes (a multiple of 8)
   const int ln = tid & 63, wv = tid >> 6;
   const int nwv = NW == 1 ? 1 : (L.T >> 6);
-  const int pair0 = row0 >> 1;
-  const int npairs = ((row0 + nrows + 1) >> 1) - pair0;
-  const uint32_t pair_bytes = 8u * (uint32_t)P.W;
-  char* const obsb = reinterpret_cast<char*>(P.obs) + (size_t)pair0 * pair_bytes;
-  const int c = ln;
-  const int h0 = 2 * c, h1 = 2 * c + 1;
-  const int u0 = h0 - (h0 >= q ? q : 0), u1 = h1 - (h1 >= q ? q : 0);
-  const bool mine = c < q && u0 >= 6 && u1 >= 6;
-  uint32_t off = (uint32_t)wv * pair_bytes + 16u * (uint32_t)c;
-  for (int i = wv; i < npairs; i += nwv) {
-    if (mine) *reinterpret_cast<float4*>(obsb + off) = make_float4(0.f, 0.f, 0.f, 0.f);
-    off += (uint32_t)nwv * pair_bytes;
+  const uint32_t nblk = (uint32_t)nrows * rb >> 6;
+  char* const base = reinterpret_cast<char*>(P.obs) + (size_t)row0 * rb;
+  uint32_t blk = (uint32_t)wv * 16u + ((uint32_t)ln >> 2);
+  uint32_t o = (blk * 64u) % rb;                           // offset of the block's start in its row
+  const uint32_t ostep = (1024u * (uint32_t)nwv) % rb;     // 16 * nwv blocks further
+  const uint32_t sub = 16u * ((uint32_t)ln & 3u);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  for (; blk < nblk; blk += 16u * (uint32_t)nwv) {
+    // no proprio of its own row (o >= 48) and none of the next row (o + 64 <= rb)
+    if (o >= 48u && o + 64u <= rb)
+      *reinterpret_cast<v4f*>(base + (size_t)blk * 64u + sub) = (v4f){0.f, 0.f, 0.f, 0.f};
+    o += ostep;
+    if (o >= rb) o -= rb;
   }
 }
-#endif
+
+// part 2: per row the 128-B window that starts at the 64-B block holding the row's first byte: the
+// tail of the previous row's VO region (s bytes), the 48 proprio bytes, the head of this row's VO
+// region.  Eight rows per wave-instruction, lane = (row, 16-B chunk); 8-B halves as in
+// row_fill_pairs: proprio from LDS, zeros inside a zero run, nothing inside kept rows.
+template <int NW>
+__device__ __forceinline__ void late_row_windows(const Params& P, const Lds& L, int tid, int row0,
+                                                 int nrows) {
+  const uint32_t rb = 4u * (uint32_t)P.W, q = rb >> 3;  // row bytes, 8-B units per row
+  const int ln = tid & 63, wv = tid >> 6;
+  const int nwv = NW == 1 ? 1 : (L.T >> 6);
+  const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
+  char* const base = reinterpret_cast<char*>(P.obs) + (size_t)row0 * rb;
+  const int ch = ln & 7;
+  for (int r = wv * 8 + (ln >> 3); r < nrows; r += 8 * nwv) {
+    const uint32_t rs = rb * (uint32_t)r;       // row start, relative to the workgroup's range
+    const uint32_t s8 = (rs & 63u) >> 3;        // units of the window that belong to row r - 1
+    const uint32_t ws = rs & ~63u;              // window start
+    // this chunk's two units: (row, unit in that row)
+    const uint32_t ua = 2u * (uint32_t)ch, ub = ua + 1u;
+    const bool pa = ua < s8, pb = ub < s8;      // in the previous row's tail
+    const int ra = pa ? r - 1 : r, rbw = pb ? r - 1 : r;
+    const uint32_t uia = pa ? q - s8 + ua : ua - s8, uib = pb ? q - s8 + ub : ub - s8;
+    const int za = L.kept[ra], zb = L.kept[rbw];   // r - 1 >= 0 whenever pa / pb (s8 = 0 at r = 0)
+    const bool proa = uia < 6u, prob = uib < 6u;
+    const float2 da = pro2[ra * 6 + (int)(proa ? uia : 5u)], db = pro2[rbw * 6 + (int)(prob ? uib : 5u)];
+    const bool va = proa | (uia >= (uint32_t)za), vb = prob | (uib >= (uint32_t)zb);
+    const float2 a = proa ? da : make_float2(0.f, 0.f), b = prob ? db : make_float2(0.f, 0.f);
+    char* const pc = base + ws + 16u * (uint32_t)ch;
+    if (va & vb) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
+    if (va != vb) *reinterpret_cast<float2*>(pc + (vb ? 8 : 0)) = vb ? b : a;
+  }
+}
 
 // The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
 // iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
@@ -693,9 +736,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       have_gw2 = true;
     }
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
-#ifdef RVO3D_DIAG
-    if (RVO3D_ABLATED(128)) early_zero_fill<NW>(P, L, tid, e0 * N, nrows);
-#endif
+    // two-phase row writer: the zeros of every block without proprio bytes leave now
+    if (two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
     kept = sweep_env<NW, true, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
@@ -704,8 +746,16 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // stores); then every other byte of the rows - proprio and zeros - in coalesced 16-B stores
   // (a lane writing its own 48 proprio bytes costs as much as the whole zero fill: 64 rows =
   // 64 partial cache lines per store instruction); the state stores drain behind them.
+  const bool two_phase = LITE && two_phase_rows(P, e0 * N, nrows);
+  if (NW > 1 && two_phase) {  // every wave's early zeros have landed before any wave writes kept rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (active) {
     if (!RVO3D_ABLATED(8)) {
+      // kept rows go over zeros this wave (or, before the sweep's barrier, this workgroup)
+      // stored earlier: those stores have to have landed
+      if (two_phase) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       write_vo_rows(P, L, tid, lbase, g, S, kept);
       RVO3D_STAMP(16);
       if (P.zf16) stage_row(P, L, tid, g, S, ptail, kept);
@@ -716,7 +766,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   __syncthreads();  // the staged rows / L.kept complete
   RVO3D_STAMP(17);
   if (!RVO3D_ABLATED(16)) {
-    if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
+    if (two_phase) late_row_windows<NW>(P, L, tid, e0 * N, nrows);
+    else if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
     else zero_fill(P, L, tid, e0 * N, nrows);
   }
   RVO3D_STAMP(8);
