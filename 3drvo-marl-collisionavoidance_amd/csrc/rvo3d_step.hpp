@@ -577,11 +577,16 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     wpi = P.wp_idx()[g];
     RVO3D_LOAD_PREV(P, g, prev);
     double yaw = P.yaw()[g], pitch = P.pitch()[g], real_len = P.real_len()[g];
-    double extra_len = P.extra_len()[g];
+    // extra_len is only ever WRITTEN by the step (drone.py:188, ir_gym.py:176): not loaded, and
+    // stored only by the drones that set it; wp_idx / arrive / dest likewise only when they change
+    bool ex_set = false;
+    double extra_len = 0.0;
     const double route_len = P.route_len()[g];
     const int npts = P.n_points()[g];
-    bool f_arrive = P.arrive()[g] != 0;
-    f_dest = P.dest()[g] != 0;
+    const int wpi_in = wpi;
+    const bool f_arrive_in = P.arrive()[g] != 0, f_dest_in = P.dest()[g] != 0;
+    bool f_arrive = f_arrive_in;
+    f_dest = f_dest_in;
 
     double speed = norm3b(S.vx, S.vy, S.vz);
     const double acc = clampd(a[0] * 1.0, -1.0, 1.0);
@@ -608,7 +613,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (f_arrive || arrived(P, p, cur)) load_wp(P, g, npts - 1, dst);
     if (arrived(P, p, cur)) {  // drone.py:116-129
       const bool at_dst = arrived(P, p, dst);
-      if (at_dst) extra_len = real_len - route_len;  // destination_arrive side effect
+      if (at_dst) { extra_len = real_len - route_len; ex_set = true; }  // destination_arrive side effect
       if (!at_dst && wpi < npts - 1) {
         wpi += 1;
         prev[0] = cur[0]; prev[1] = cur[1]; prev[2] = cur[2];
@@ -629,6 +634,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (f_arrive) {
       if (arrived(P, p, dst)) {
         extra_len = real_len - route_len;
+        ex_set = true;
         if (!f_dest) { f_dest = true; dest_r = true; }
       }
     }
@@ -640,9 +646,11 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (S.x < 0 || S.x > P.cold().map[0] || S.y < 0 || S.y > P.cold().map[1] || S.z < 0 || S.z > P.cold().map[2])
       collision = true;  // drone.drone_out_map, drone.py:213-225
     // final for this step unless the drone is reset below
-    P.yaw()[g] = yaw; P.pitch()[g] = pitch; P.real_len()[g] = real_len; P.extra_len()[g] = extra_len;
-    P.wp_idx()[g] = wpi;
-    P.arrive()[g] = f_arrive ? 1 : 0; P.dest()[g] = f_dest ? 1 : 0;
+    P.yaw()[g] = yaw; P.pitch()[g] = pitch; P.real_len()[g] = real_len;
+    if (ex_set) P.extra_len()[g] = extra_len;
+    if (wpi != wpi_in) P.wp_idx()[g] = wpi;
+    if (f_arrive != f_arrive_in) P.arrive()[g] = f_arrive ? 1 : 0;
+    if (f_dest != f_dest_in) P.dest()[g] = f_dest ? 1 : 0;
     P.info[g] = f_arrive ? 1 : 0;
     P.finish[g] = f_dest ? 1 : 0;
   }
