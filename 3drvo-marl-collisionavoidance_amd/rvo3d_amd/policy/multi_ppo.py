@@ -47,14 +47,47 @@ from torch.optim import Adam
 
 
 def gae_scan(rew, val, cut, gamma=0.99, lam=0.97):
-    """Reverse scan over time.  rew, val: float [T, ...]; cut: bool [T, ...], True where
-    the path ends after step t (bootstrap 0).  Returns (adv, ret) float32.
+    """GAE over time, all columns at once.  rew, val: float [T, ...]; cut: bool [T, ...], True
+    where the path ends after step t (bootstrap 0; the end of the buffer ends every path).
+    Returns (adv, ret) float32.
 
     multi_PPObuf.finish_path (multi_ppo.py:68-77) per path:
         deltas = r_t + gamma * V_{t+1} - V_t,  V_end = 0
         adv    = discount_cumsum(deltas, gamma * lam)
         ret    = discount_cumsum(rews + [0], gamma)[:-1]
-    """
+    A discounted sum to the end of the path is a difference of two reverse prefix sums:
+        sum_{s = t .. end(t)} c^(s - t) x_s = (C_t - C_{end(t) + 1}) / c^t,  C_t = sum_{s >= t} c^s x_s
+    in float64 (np.append promotes the reference's float32 buffers as well), so the whole scan is a
+    dozen tensor ops instead of a Python loop over T.  Terms of C_t carry weights <= c^t, so the
+    difference loses nothing to cancellation; c^T stays far above the float64 underflow for any
+    buffer length in use (0.96^4000 = 1e-71).  `gae_scan_loop` is the step-by-step form it is
+    tested against."""
+    T = rew.shape[0]
+    dev = rew.device
+    r, v = rew.to(torch.float64), val.to(torch.float64)
+    cutb = cut.to(torch.bool).clone()
+    cutb[T - 1] = True
+    keep = (~cutb).to(torch.float64)
+    v_next = torch.cat([v[1:], torch.zeros_like(v[:1])], dim=0) * keep   # V_{t+1}, 0 behind a cut
+    delta = r + gamma * v_next - v
+    # end(t) + 1 = index behind the first cut at or after t
+    shape1 = (T,) + (1,) * (rew.dim() - 1)
+    idx = torch.arange(T, device=dev).view(shape1).expand_as(cutb)
+    nxt = torch.where(cutb, idx + 1, torch.full_like(idx, T))
+    end1 = torch.flip(torch.cummin(torch.flip(nxt, [0]), dim=0).values, [0])  # [T, ...] in 1..T
+
+    def disc(x, c):
+        w = torch.pow(torch.full((T,), float(c), dtype=torch.float64, device=dev),
+                      torch.arange(T, dtype=torch.float64, device=dev)).view(shape1)
+        C = torch.flip(torch.cumsum(torch.flip(x * w, [0]), dim=0), [0])
+        C = torch.cat([C, torch.zeros_like(C[:1])], dim=0)                   # C_T = 0
+        return (C[:-1] - torch.gather(C, 0, end1)) / w
+
+    return disc(delta, gamma * lam).to(torch.float32), disc(r, gamma).to(torch.float32)
+
+
+def gae_scan_loop(rew, val, cut, gamma=0.99, lam=0.97):
+    """The same scan, one step at a time (reference form; tests compare gae_scan with it)."""
     T = rew.shape[0]
     r, v = rew.to(torch.float64), val.to(torch.float64)
     keep = (~cut.to(torch.bool)).to(torch.float64)
@@ -375,10 +408,11 @@ class multi_ppo:
         ratio = torch.exp(logp - logp_old)
         clip_adv = torch.clamp(ratio, 1 - self.clip_ratio, 1 + self.clip_ratio) * adv
         loss_pi = -(torch.min(ratio * adv, clip_adv)).mean()
-        approx_kl = (logp_old - logp).mean().item()
-        ent = pi.entropy().mean().item()
         clipped = ratio.gt(1 + self.clip_ratio) | ratio.lt(1 - self.clip_ratio)
-        clipfrac = clipped.float().mean().item()
+        # the three diagnostics in ONE device-to-host transfer (the reference's three .item()
+        # calls are three synchronisations per optimizer step)
+        approx_kl, ent, clipfrac = torch.stack([(logp_old - logp).mean().detach(), pi.entropy().mean().detach(),
+                                                clipped.float().mean()]).tolist()
         return loss_pi, dict(kl=approx_kl, ent=ent, cf=clipfrac)
 
     def save_model(self, index=0):  # multi_ppo.py:406-420

@@ -88,6 +88,21 @@ def test_gae_matches_multi_PPObuf():
     np.testing.assert_array_equal(R2[:, 2, 0].numpy(), ret.numpy())
 
 
+def test_vectorised_gae_equals_the_step_by_step_scan():
+    """gae_scan (two reverse prefix sums) against gae_scan_loop (one step at a time) on random
+    [T, E, N] data with random per-env cuts, long buffers included."""
+    from rvo3d_amd.policy import gae_scan_loop
+    g = torch.Generator().manual_seed(3)
+    for T, E, N in ((1, 2, 3), (7, 5, 2), (300, 6, 4), (2000, 2, 2)):
+        rew = torch.randn(T, E, N, generator=g) * 3
+        val = torch.randn(T, E, N, generator=g) * 2
+        cut = (torch.rand(T, E, generator=g) < 0.05)[:, :, None].expand(T, E, N)
+        a1, r1 = gae_scan(rew, val, cut, 0.99, 0.97)
+        a2, r2 = gae_scan_loop(rew, val, cut, 0.99, 0.97)
+        np.testing.assert_allclose(a1.numpy(), a2.numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(r1.numpy(), r2.numpy(), rtol=1e-6, atol=1e-6)
+
+
 def test_rollout_buffer_cut_rules():
     buf = RolloutBuffer(4, 2, 3, 21, 3, "cpu", 0.99, 0.97)
     for t in range(4):
