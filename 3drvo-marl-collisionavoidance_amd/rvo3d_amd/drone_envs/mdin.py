@@ -34,7 +34,7 @@ class _DroneView:
         self.rvo_vel = [0, 0, 0]  # drawing-only attribute the trainer writes (multi_ppo.py:207)
 
     def _s(self, k):
-        return self._o._state()[k][0, self.id].cpu().numpy()
+        return self._o._state()[k][0, self.id]
 
     vel = property(lambda self: self._s("vel"))
     state = property(lambda self: self._s("pos"))
@@ -64,8 +64,10 @@ class _IrGym:
         self._cache = None
 
     def _state(self):
+        """Host copy of the whole state, fetched once per step / reset (every attribute read of
+        every `drone_list[i]` between two steps is served from it)."""
         if self._cache is None:
-            self._cache = self._env.get_state()
+            self._cache = {k: v.cpu().numpy() for k, v in self._env.get_state().items()}
         return self._cache
 
     def _ragged(self, obs, cnt):
@@ -94,10 +96,10 @@ class _IrGym:
         return list(self._env.des_vel()[0].cpu().numpy())
 
     def indicators_deviation(self):                 # ir_gym.py:414-416
-        return list(self._state()["max_dev"][0].cpu().numpy())
+        return list(self._state()["max_dev"][0])
 
     def indicators_extra_len(self):                 # ir_gym.py:418-420
-        return list(self._state()["extra_len"][0].cpu().numpy())
+        return list(self._state()["extra_len"][0])
 
     def render(self, *a, **k):                      # plotting is out of scope (env_plot.py)
         return None

@@ -462,6 +462,13 @@ def test_mdin_list_api_config1_world4():
             assert len(o) == 12 + 9 * k
             assert close(o, fx["obs"][t][i][:len(o)]).all()
         assert eq_nan(np.asarray(reward_list), fx["reward"][t]).all()   # float64, bit for bit (mdin.py:28)
+        # the trainer's reach-through (multi_ppo.py:202, 212, 246): drone_list[i].vel / .state, indicators_*
+        for i in (0, 3):
+            np.testing.assert_allclose(env.ir_gym.drone_list[i].vel, fx["state_vel"][t][i], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(env.ir_gym.drone_list[i].state, fx["state_pos"][t][i], rtol=1e-12, atol=1e-12)
+            assert env.ir_gym.drone_list[i].i == int(fx["state_wp_idx"][t][i])
+        np.testing.assert_allclose(env.ir_gym.indicators_deviation(), fx["state_max_dev"][t], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(env.ir_gym.indicators_extra_len(), fx["state_extra_len"][t], rtol=1e-12, atol=1e-12)
         for i in [i for i, d in enumerate(done_list) if d]:
             env.drone_reset_one(False, i)
     with pytest.raises(AssertionError):
