@@ -138,6 +138,10 @@ def main():
                     help="every timed step also runs the trainer's gradient-bucket all-reduce + KL mean "
                          "(default whenever --gpus > 1)")
     ap.add_argument("--no-grad-allreduce", action="store_true", help="N > 1 without the collective")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
+                    "rehearse the N > 1 code path where the ranks cannot have a GPU each)")
+    ap.add_argument("--all-ranks-on-device", type=int, default=None,
+                    help="rehearsal only: every rank uses this one GPU (needs --backend gloo)")
     args = ap.parse_args()
 
     from rvo3d_amd import BatchedDroneEnv, _lib, sharding, synthetic_actions, synthetic_world
@@ -152,10 +156,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
+    if args.all_ranks_on_device is not None and args.backend == "nccl" and world > 1:
+        raise SystemExit("--all-ranks-on-device needs --backend gloo (RCCL wants one GPU per rank)")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist = sharding.init_process_group("nccl", dev)  # nccl == RCCL on ROCm
+        dist = sharding.init_process_group(args.backend, dev)  # nccl == RCCL on ROCm
 
     E, N, nm, nb = args.envs, args.drones, args.nm, args.buildings
     K, W = args.steps, args.warmup
@@ -193,6 +200,14 @@ def main():
         one_step(W + t)
     barrier()
     elapsed = sharding.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    elapsed_step_only = None
+    if bucket is not None:  # the same K steps without the collective, for comparison (not `value`)
+        barrier()
+        t1 = time.perf_counter()
+        for t in range(K):
+            env.step(acts[(W + t) % n_act], autoreset=autoreset)
+        barrier()
+        elapsed_step_only = sharding.max_over_ranks(dist, time.perf_counter() - t1, dev)
 
     # kernel time: HIP events on the launch stream (torch's current stream), one pair per launch
     stream = torch.cuda.current_stream(dev)
@@ -213,7 +228,8 @@ def main():
             bucket.step()
             b.record(stream)
         torch.cuda.synchronize()
-        coll = dict(ranks_seen=bucket.ranks_seen(), backend="nccl (RCCL)" if world > 1 else "none (1 rank)",
+        coll = dict(ranks_seen=bucket.ranks_seen(),
+                    backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none (1 rank)",
                     allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
                     bucket_bytes=bucket.nbytes, per_step="gradient bucket all-reduce + KL mean all-reduce "
                     "(multi_ppo._allreduce_grads / update), once per timed env step")
@@ -263,6 +279,8 @@ def main():
                          "bytes_per_drone_step": B},
         }
         if coll is not None:
+            coll["value_env_step_only"] = round(total_units / elapsed_step_only, 1)
+            coll["ms_per_step_env_step_only"] = round(elapsed_step_only / K * 1e3, 4)
             out["collective"] = coll
             out["config"]["workload"] += "; + gradient-bucket all-reduce and KL mean per step"
         if not args.no_cpu_baseline and world == 1:  # reported once, at N = 1
