@@ -192,7 +192,7 @@ __device__ __forceinline__ void valid_offsets(int N, int d, uint32_t valid[NW]) 
 
 // Stage G arithmetic, shared by every place that decides "possibly in range" (gate_word,
 // regate_resets): acc = dx^2 + dy^2 + dz^2 - t', one fma chain starting from -t' with
-// t' = nextafter(T10 + band): the pair is possibly in range iff acc < 0 (d2 < t' <=> d2 <= t10f up to
+// t' = nextafter(T10 + band): the pair is possibly in range iff acc < 0 (d2 < t' <=> d2 <= T10 + band up to
 // the rounding of the chain, which the doubled band covers), i.e. iff the SIGN BIT of acc is set -
 // one v_alignbit per pair shifts it into the word, no compare / select / or.
 __device__ __forceinline__ float gate_acc(float dx, float dy, float dz, float t10n) {

@@ -254,8 +254,8 @@ __device__ __forceinline__ void late_row_windows(const Params& P, const Lds& L, 
 }
 
 // The kept VO rows of one observation row (np.round(., 2) of [PAA, rel, alpha, min_dis,
-// iet] per row, ascending urgency), its vo_count, and the bookkeeping of the zero run
-// behind them (written by zero_fill()).
+// iet] per row, ascending urgency) and its vo_count.  The zeros behind them are the row
+// writers' business (row_fill_pairs / the two-phase writer / zero_fill).
 __device__ __forceinline__ void write_vo_rows(const Params& P, const Lds& L, int tid, int lbase,
                                               int g, const Drone& S, int kept) {
   float* o = P.obs + (size_t)g * P.W;
