@@ -404,10 +404,13 @@ __device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, 
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
-// One-wave workgroups (N <= 64) are register-limited: 128 VGPRs = 4 waves per SIMD, i.e. the
-// 4096 waves of 64 x 4096 are all resident at once.  Larger N is LDS-limited (3 per SIMD).
+// 128 VGPRs = 4 waves per SIMD.  One-wave workgroups (N <= 64): the 4096 waves of 64 x 4096 are
+// all resident at once.  N <= 256 (one env per workgroup of 2 or 4 waves): the fourth wave per
+// SIMD is what lets 4 workgroups of 256 drones (40 KB of LDS each) share a CU, and shortens the
+// tail for the shapes in between (100 drones x 2048 envs: 67.8 -> 55.6 us) - at the price of
+// some spills above 128 drones.  N > 256 is LDS-bound to one or two workgroups per CU: 3 per SIMD.
 #ifndef RVO3D_WAVES_ATTR
-#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu((NW == 1 || NFIX >= 128) ? 4 : 3)))
+#define RVO3D_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NW <= 4 ? 4 : 3)))
 #endif
 
 // The whole environment step, one launch.
