@@ -182,6 +182,7 @@ class multi_ppo:
             warnings.warn("max_update_num only applies to the reference-order update "
                           "(reference_order=True or update(data_list)); the pooled update ignores it")
         self.max_update_num = 10 if max_update_num is None else int(max_update_num)  # multi_ppo.py:101
+        self._flat = None  # multi-rank gradient bucket (see _bucket)
         self._check_equal_shards()
         # The reference's RVO reward is inf / nan while a drone sits within 0.4 m of its
         # waypoint (ir_gym.py:88, survey Q9) and would poison GAE; by default such rewards
@@ -285,18 +286,35 @@ class multi_ppo:
                              "drones): shard the envs equally (sharding.shard_env_range needs a "
                              "total divisible by the world size)")
 
+    def _bucket(self):
+        """Multi-rank: every gradient lives in ONE flat buffer (each p.grad is a view of it), so the
+        collective of an optimizer step is a single in-place all-reduce - no gather before, no scatter
+        after.  Built on first use; zero_grad keeps the views (set_to_none=False, see _zero)."""
+        if self._flat is None:
+            params = list(self.ac.parameters())
+            flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+            off = 0
+            for p in params:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is not None:
+                    g.copy_(p.grad)
+                p.grad = g
+                off += p.numel()
+            self._flat = flat
+        return self._flat
+
+    def _zero(self, opt):
+        """optimizer.zero_grad as the reference calls it; with several ranks the gradients stay
+        views of the bucket (zeroed in place)."""
+        opt.zero_grad(set_to_none=self._world() == 1)
+
     def _allreduce_grads(self):
         d = self.dist
         if d is None or not d.is_initialized() or d.get_world_size() == 1:
             return
-        grads = [p.grad for p in self.ac.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = self._bucket()
         d.all_reduce(flat)  # one bucket per optimizer step (0.7 - 2.7 MB: latency-bound on xGMI)
         flat /= d.get_world_size()
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
 
     def _mean_over_ranks(self, x: float) -> float:
         d = self.dist
@@ -336,7 +354,7 @@ class multi_ppo:
             stop = False
             for idx in self._batches(n):
                 mb = {k: v[idx] for k, v in data.items()}
-                self.pi_optimizer.zero_grad()
+                self._zero(self.pi_optimizer)
                 loss_pi, pi_info = self.compute_loss_pi(mb)
                 kl = self._mean_over_ranks(pi_info["kl"])
                 if kl > self.target_kl:  # KL check before the step
@@ -353,7 +371,7 @@ class multi_ppo:
         for i in range(self.train_v_iters):  # multi_ppo.py:371-376
             for idx in self._batches(n):
                 mb = {k: v[idx] for k, v in data.items()}
-                self.vf_optimizer.zero_grad()
+                self._zero(self.vf_optimizer)
                 loss_v = self.compute_loss_v(mb)
                 loss_v.backward()
                 self._allreduce_grads()
@@ -376,7 +394,7 @@ class multi_ppo:
                 continue
             steps = 0
             for i in range(self.train_pi_iters):
-                self.pi_optimizer.zero_grad()
+                self._zero(self.pi_optimizer)
                 loss_pi, pi_info = self.compute_loss_pi(data)
                 kl = self._mean_over_ranks(pi_info["kl"])
                 if kl > self.target_kl:
@@ -388,7 +406,7 @@ class multi_ppo:
                 steps += 1
             pi_steps.append(steps)
             for i in range(self.train_v_iters):
-                self.vf_optimizer.zero_grad()
+                self._zero(self.vf_optimizer)
                 loss_v = self.compute_loss_v(data)
                 loss_v.backward()
                 self._allreduce_grads()
