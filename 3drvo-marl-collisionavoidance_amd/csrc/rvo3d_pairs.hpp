@@ -302,6 +302,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
                             : (cand_t)((unsigned long long)gw[CW * w] |
                                        ((unsigned long long)gw[CW * w + (CW - 1)] << 32));
       if (RVO3D_ABLATED(64)) cand = 0;
+      cand_t keep = 0;  // candidates with somebody possibly approaching (ROWS: filed for the next sweep A)
 #ifdef RVO3D_DIAG
       if (P.dbg && ROWS) {  // diagnostics build: X1 candidates of this workgroup in the rows sweep (sum, max per lane)
         const int c = CW == 1 ? __builtin_popcount((uint32_t)cand) : __builtin_popcountll(cand);
@@ -383,10 +384,17 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
           const int oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                   \
           pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
           pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
+          if (ROWS) keep |= (cand_t)((fr | ai | aj) & 1) << kbit;                             \
         }
         bool pi0, pj0, pi1, pj1;
-        RVO3D_X1_HALF(x, jd0, pi0, pj0)
-        RVO3D_X1_HALF(y, jd1, pi1, pj1)
+        {
+          const int kbit = kb0;
+          RVO3D_X1_HALF(x, jd0, pi0, pj0)
+        }
+        {
+          const int kbit = kb1;
+          RVO3D_X1_HALF(y, jd1, pi1, pj1)
+        }
 #undef RVO3D_X1_HALF
         pi1 &= two; pj1 &= two;
         if (NW == 1) {
@@ -397,6 +405,14 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         }
         if (pj0) atomicOr(&L.mask2[(el * N + jd0) * NW + (d >> 6)], 1ull << (d & 63));
         if (pj1) atomicOr(&L.mask2[(el * N + jd1) * NW + (d >> 6)], 1ull << (d & 63));
+      }
+      // The words filed for the next step's sweep A (same state, another action) keep only the
+      // pairs in which somebody is possibly approaching: "approaching" does not depend on the
+      // action, and sweep A (no touch test) asks nothing of the others - about half of the in-range
+      // pairs drop out of its X1.
+      if (ROWS) {
+        if (CW == 1) gw[0] = (uint32_t)keep;
+        else { gw[CW * w] = (uint32_t)keep; gw[CW * w + (CW - 1)] = (uint32_t)((unsigned long long)keep >> 32); }
       }
     }
   }
