@@ -429,7 +429,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 #endif
   if (active && !RVO3D_ABLATED(32)) {
     const int lbase = el * N;
-#pragma unroll
+#pragma unroll  // (a rolled loop over the words is smaller but 4 % slower at 128 and 256 drones)
     for (int w = 0; w < NW; ++w) {
       unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
       while (m2) {  // stage X2: exact, requested pairs only
