@@ -372,9 +372,16 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
     if (C.bgx > 0) {
       // cell (ix, iy) = [ix*cs, (ix+1)*cs] x [iy*cs, (iy+1)*cs], widened by 1e-3 m (the device
       // finds the cell with floor(x / cs) in floating point) and unbounded at the map's edge
-      // (clamped lookups); a building is listed where its 5 m gate circle reaches the cell
+      // (clamped lookups); a building is listed where a drone inside the cell could hit it:
+      // within the 5 m gate AND within (largest drone radius + building radius) of its axis
+      // (rvo_inter.py:104, :207) - with 0.2 m drones that is 2 cells per building instead of 5
       const int K = rvo3d::kBgridK;
-      const double cs = 1.0 / C.bg_inv, reach = 5.0 + 1e-3;
+      const double cs = 1.0 / C.bg_inv;
+      double rmax = 0.0;
+      for (size_t g = 0; g < EN; ++g) {
+        if (rad[g] != rad[g]) rmax = INFINITY;  // a NaN radius: no pruning beyond the gate
+        else if (rad[g] > rmax) rmax = rad[g];
+      }
       grid.assign((size_t)C.bgx * C.bgy * (K + 1), 0);
       for (int ix = 0; ix < C.bgx; ++ix)
         for (int iy = 0; iy < C.bgy; ++iy) {
@@ -385,6 +392,9 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
           bool overflow = false;
           for (int b = 0; b < C.nb && !overflow; ++b) {
             const double bx = buildings[4 * b], by = buildings[4 * b + 1];
+            double reach = rmax + buildings[4 * b + 3];
+            if (!(reach < 5.0)) reach = 5.0;  // the gate (also a NaN radius)
+            reach += 1e-3;
             const double dx = bx < x0 ? x0 - bx : (bx > x1 ? bx - x1 : 0.0);
             const double dy = by < y0 ? y0 - by : (by > y1 ? by - y1 : 0.0);
             if (!(dx * dx + dy * dy > reach * reach)) {  // also keeps NaN centres

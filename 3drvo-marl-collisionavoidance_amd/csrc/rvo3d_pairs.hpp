@@ -209,7 +209,7 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t m, float acc) {
 // highest offset of the word down, so that bit b of the result is offset 32w + b + 1.
 // TOUCHONLY: possibly touching (and in range), with the in-range word on the side; else:
 // possibly in range.  Bits above the word's last offset may be set: callers mask with valid[].
-template <bool TOUCHONLY>
+template <bool TOUCHONLY, bool UNIFORM_R = false>
 __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int o0, int w, int H,
                                               float mex, float mey, float mez, float mer,
                                               uint32_t* range_out = nullptr) {
@@ -218,6 +218,11 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
   const v2f tn = {P.t10n, P.t10n};
   const int kend = (H - 32 * w) < 32 ? (H - 32 * w) : 32;  // offsets in this word
   uint32_t mr = 0u, mt = 0u;
+  // one radius for every drone (the usual world): the touch bound is the same for all pairs,
+  // the very value the per-pair arithmetic below would produce
+  const v2f ru = sr + sr;
+  const v2f rcu = __builtin_elementwise_fma(ru * ru, (v2f){1.00001f, 1.00001f},
+                                            (v2f){P.bandn, P.bandn});
 #pragma unroll RVO3D_G_UNROLL
   for (int b = (kend - 1) & ~1; b >= 0; b -= 2) {
     const int o = o0 + 32 * w + b + 1;
@@ -231,9 +236,12 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
     if (TOUCHONLY) {
       // possibly touching: d2 <= (r + mr)^2 * 1.00001 + band, as the sign of
       // (d2 - t') - ((r + mr)^2 * 1.00001 + band - t')
-      const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
-      const v2f rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
-                                               (v2f){P.bandn, P.bandn});
+      v2f rc = rcu;
+      if (!UNIFORM_R) {
+        const v2f rs = (v2f){L.w[WR][o], L.w[WR][o + 1]} + sr;
+        rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f},
+                                       (v2f){P.bandn, P.bandn});
+      }
       const v2f at = acc - rc;
       mt = shift_in_sign(shift_in_sign(mt, at.y), at.x);
     }
@@ -477,7 +485,8 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
       gw[w] = valid[w];
       if (!far) {
         uint32_t rng;
-        cand = gate_word<true>(P, L, o0, w, H, mex, mey, mez, mer, &rng) & valid[w];
+        cand = (P.uniform_rp ? gate_word<true, true>(P, L, o0, w, H, mex, mey, mez, mer, &rng)
+                             : gate_word<true, false>(P, L, o0, w, H, mex, mey, mez, mer, &rng)) & valid[w];
         gw[w] = rng & valid[w];
       }
       while (cand) {  // exact decision, both drones of the pair

@@ -32,27 +32,24 @@ __device__ __forceinline__ bool building_hit(const Params& P, const Drone& S) {
     int ix = (int)__builtin_floor(S.x * inv), iy = (int)__builtin_floor(S.y * inv);
     ix = ix < 0 ? 0 : (ix > gx - 1 ? gx - 1 : ix);
     iy = iy < 0 ? 0 : (iy > gy - 1 ? gy - 1 : iy);
-    // the cell's whole list in two 16-B loads (kBgridK + 1 = 16 u16, 32-B aligned), then the
-    // records of up to four listed buildings per round trip (index 0 pads the batch: testing
-    // a building twice changes nothing)
-    const uint4* const cell4 = reinterpret_cast<const uint4*>(
-        P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1));
-    const uint4 c0 = cell4[0], c1 = cell4[1];
-    const uint32_t cw[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const int cnt = (int)(cw[0] & 0xffffu);
+    // the count and the first seven entries in one 16-B load (lists are short: most cells have
+    // none or one), the records of two listed buildings per round trip (entry 1 pads the batch:
+    // testing a building twice changes nothing); longer lists are walked from memory
+    const uint16_t* const cell = P.cold().bgrid + (size_t)(ix * gy + iy) * (kBgridK + 1);
+    const uint4 c0 = *reinterpret_cast<const uint4*>(cell);
+    const int cnt = (int)(c0.x & 0xffffu);
     if (cnt != 0xffff) {
-      // entry k (1-based: 1..cnt) is halfword k of the 16
-#define RVO3D_CELL_IDX(k) ((int)((cw[(k) >> 1] >> (((k) & 1) * 16)) & 0xffffu))
-#pragma unroll
-      for (int k0 = 1; k0 <= kBgridK; k0 += 4) {
-        if (k0 > cnt) break;
-        int bi[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bi[u] = (k0 + u <= cnt && k0 + u <= kBgridK) ? RVO3D_CELL_IDX(k0 + u) : RVO3D_CELL_IDX(1);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hit |= building_test(bld, bi[u], S, T5);
+      if (cnt >= 1) {
+        const int b0 = (int)(c0.x >> 16), b1 = cnt >= 2 ? (int)(c0.y & 0xffffu) : b0;
+        hit |= building_test(bld, b0, S, T5);
+        hit |= building_test(bld, b1, S, T5);
       }
-#undef RVO3D_CELL_IDX
+      if (cnt >= 3) {
+        const int b0 = (int)(c0.y >> 16), b1 = cnt >= 4 ? (int)(c0.z & 0xffffu) : b0;
+        hit |= building_test(bld, b0, S, T5);
+        hit |= building_test(bld, b1, S, T5);
+      }
+      for (int k = 5; k <= cnt; ++k) hit |= building_test(bld, (int)cell[k], S, T5);
       return hit;
     }
   }
@@ -216,8 +213,11 @@ __device__ __forceinline__ void early_zero_blocks(const Params& P, const Lds& L,
   typedef float v4f __attribute__((ext_vector_type(4)));
   for (; blk < nblk; blk += 16u * (uint32_t)nwv) {
     // no proprio of its own row (o >= 48) and none of the next row (o + 64 <= rb)
+    // streaming stores: whole 64-B blocks nobody reads back (-1 %; the windows of part 2, whose
+    // lines are shared with the kept rows, are faster as ordinary stores)
     if (o >= 48u && o + 64u <= rb)
-      *reinterpret_cast<v4f*>(base + (size_t)blk * 64u + sub) = (v4f){0.f, 0.f, 0.f, 0.f};
+      __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f},
+                                  reinterpret_cast<v4f*>(base + (size_t)blk * 64u + sub));
     o += ostep;
     if (o >= rb) o -= rb;
   }

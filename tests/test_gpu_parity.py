@@ -368,6 +368,30 @@ def test_per_drone_radius_and_priority(N, E):
     assert st["resets"] > 0, st
 
 
+@pytest.mark.parametrize("N,E,nb,rmaxb", [(32, 48, 10, 1.5), (48, 24, 40, 1.5), (64, 16, 12, 6.5), (100, 4, 300, 0.6)])
+def test_building_lists_short_long_and_overflowing(N, E, nb, rmaxb):
+    """The per-cell building lists (a building is listed where a drone of the largest radius
+    could touch it, at most the 5 m gate of rvo_inter.py:104): sparse lists, lists longer than
+    the four entries tested from registers, cells that overflow (all buildings tested), building
+    radii beyond the gate (r + br > 5: the gate, not the radius, decides) and per-drone radii."""
+    rng = np.random.default_rng(100 + N)
+    L = 24.0
+    world = synthetic_world(E, N, (L, L, 8.0), min_sep=0.8, seed=41, nb=nb)
+    b = world.buildings.copy()
+    # unrounded axes / radii / heights: with 2-decimal buildings AND 2-decimal start positions,
+    # dis == r + br holds exactly for several percent of the (drone, building) pairs of a
+    # crowded map - knife edges by construction, which would only dilute the comparison
+    b[:, :2] += rng.uniform(-0.004, 0.004, (nb, 2))
+    b[:, 3] = rng.uniform(0.05, rmaxb, nb)
+    b[:, 2] = rng.uniform(0.5, 9.0, nb)      # some lower than the drones fly, some above the map
+    world.buildings = b
+    radius = np.round(rng.uniform(0.1, 0.9, (E, N)), 2)
+    st = run_vs_oracle(world, T=25, autoreset=True, radius=radius, name=f"buildings/{N}x{E}x{nb}")
+    assert st["done"] > 0 and st["resets"] > 0, st
+    st = run_vs_oracle(world, T=15, autoreset=False, radius=0.2, seed=9, name=f"buildings/{N}x{E}x{nb}_uniform")
+    assert st["done"] > 0, st
+
+
 def test_cfg2_velocity_like_actions():
     """Same world as config 2 with trainer-like candidate velocities: VO rows are common."""
     st = run_vs_oracle(synthetic_world(256, 16, (20, 20, 8), seed=5), T=40, vlike=True,
