@@ -77,7 +77,12 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) {
   return x < lo ? lo : (x > hi ? hi : x);
 }
 __device__ __forceinline__ double np_mod(double a, double b) {  // npy_divmod remainder
-  double m = fmod(a, b);
+  // fmod without the library call where it is plain: |a| < b is a itself, b <= a < 2b is
+  // a - b, exact (Sterbenz) - the yaw of a step, [0, 360) plus at most 90 either way, never
+  // leaves that range (tests/test_numeric_shortcuts.py)
+  double m;
+  if (b > 0.0 && a > -b && a < 2.0 * b) m = a >= b ? a - b : a;
+  else m = fmod(a, b);
   if (m != 0.0) {
     if ((b < 0.0) != (m < 0.0)) m += b;
   } else {

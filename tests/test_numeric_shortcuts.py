@@ -97,3 +97,23 @@ def test_cone_prefilter_is_conservative():
     inside = alpha_c > beta_c
     assert rejected.sum() > 1000 and inside.sum() > 1000
     assert not (rejected & inside).any()
+
+
+def test_fmod_shortcut_for_one_period_either_side():
+    """np_mod's fast path (rvo3d_math.hpp): fmod(a, b) is a for |a| < b and a - b, exactly, for
+    b <= a < 2b; the remainder logic of npy_divmod follows unchanged."""
+    rng = np.random.default_rng(5)
+    b = 360.0
+    a = np.concatenate([rng.uniform(-360, 720, 200000), np.array([0.0, -0.0, 360.0, 359.99999999999994, 360.00000000000006,
+                                                                   719.9999999999999, -359.99999999999994, 90.0, 450.0, -90.0]),
+                        np.round(rng.uniform(-360, 720, 50000), 2)])
+    a = a[(a > -b) & (a < 2 * b)]
+    fast = np.where(a >= b, a - b, a)
+    ref = np.fmod(a, b)
+    assert np.array_equal(fast, ref) and np.array_equal(np.signbit(fast), np.signbit(ref))
+    # and the whole remainder, against numpy's own
+    m = fast.copy()
+    nz = m != 0
+    m[nz & (m < 0)] += b
+    m[~nz] = 0.0
+    assert np.array_equal(m, np.mod(a, b))
