@@ -20,6 +20,9 @@ update) - is put INSIDE every timed step whenever N > 1 (or with
 policy of BASELINE config 3 (0.74 MB fp32).  That is the worst case - one optimizer
 step per env step; training does one per several hundred - so the multi-GPU record
 contains real xGMI traffic and the scaling efficiency read from it is a lower bound.
+The collective is issued on a second HIP stream (it depends on nothing the env step
+produces), so it overlaps the next env step the way it would overlap a backward pass;
+--serial-collective puts it on the step's stream instead.
 At N = 1 the step is the env step alone (the headline).
 
 Rank 0 prints ONE JSON line with the contract fields plus
@@ -138,6 +141,9 @@ def main():
                     help="every timed step also runs the trainer's gradient-bucket all-reduce + KL mean "
                          "(default whenever --gpus > 1)")
     ap.add_argument("--no-grad-allreduce", action="store_true", help="N > 1 without the collective")
+    ap.add_argument("--serial-collective", action="store_true",
+                    help="issue the collective on the env step's own stream (default: a second HIP stream, so "
+                         "that it overlaps the next env step as it would overlap any other compute)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 code path where the ranks cannot have a GPU each)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
@@ -180,10 +186,21 @@ def main():
     bucket = GradBucket(env, dist) if with_coll else None
     torch.cuda.synchronize()
 
+    # The collective depends on nothing the env step produces (and vice versa): it goes to its own
+    # HIP stream and overlaps the following env step(s); both are inside the timed region.
+    side = None
+    if bucket is not None and not args.serial_collective:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
     def one_step(t):
         env.step(acts[t % n_act], autoreset=autoreset)
         if bucket is not None:
-            bucket.step()
+            if side is not None:
+                with torch.cuda.stream(side):
+                    bucket.step()
+            else:
+                bucket.step()
 
     def barrier():
         if dist is not None:
@@ -231,6 +248,7 @@ def main():
         coll = dict(ranks_seen=bucket.ranks_seen(),
                     backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none (1 rank)",
                     allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
+                    overlapped=side is not None,
                     bucket_bytes=bucket.nbytes, per_step="gradient bucket all-reduce + KL mean all-reduce "
                     "(multi_ppo._allreduce_grads / update), once per timed env step")
 
@@ -282,7 +300,8 @@ def main():
             coll["value_env_step_only"] = round(total_units / elapsed_step_only, 1)
             coll["ms_per_step_env_step_only"] = round(elapsed_step_only / K * 1e3, 4)
             out["collective"] = coll
-            out["config"]["workload"] += "; + gradient-bucket all-reduce and KL mean per step"
+            out["config"]["workload"] += ("; + gradient-bucket all-reduce and KL mean per step" +
+                                          (" on a second stream" if side is not None else ""))
         if not args.no_cpu_baseline and world == 1:  # reported once, at N = 1
             out["cpu_baseline"] = cpu_baseline(N, nm, tuple(args.map))
         print(json.dumps(out), flush=True)
