@@ -253,6 +253,56 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
   return mr;
 }
 
+// The offsets one X1 loop walks, as a bit set of CW words (32 offsets each): pop-lowest, test, set.
+template <int CW> struct OffsetSet;
+template <> struct OffsetSet<1> {
+  uint32_t a;
+  __device__ __forceinline__ static OffsetSet load(const uint32_t* g) { return {g[0]}; }
+  __device__ __forceinline__ static OffsetSet none() { return {0u}; }
+  __device__ __forceinline__ bool any() const { return a != 0u; }
+  __device__ __forceinline__ int lowest() const { return __builtin_ctz(a); }
+  __device__ __forceinline__ void drop() { a &= a - 1u; }
+  __device__ __forceinline__ void add(int b, int on) { a |= (uint32_t)(on & 1) << b; }
+  __device__ __forceinline__ void store(uint32_t* g) const { g[0] = a; }
+  __device__ __forceinline__ int count() const { return __builtin_popcount(a); }
+};
+template <> struct OffsetSet<2> {
+  unsigned long long a;
+  __device__ __forceinline__ static OffsetSet load(const uint32_t* g) {
+    return {(unsigned long long)g[0] | ((unsigned long long)g[1] << 32)};
+  }
+  __device__ __forceinline__ static OffsetSet none() { return {0ull}; }
+  __device__ __forceinline__ bool any() const { return a != 0ull; }
+  __device__ __forceinline__ int lowest() const { return __builtin_ctzll(a); }
+  __device__ __forceinline__ void drop() { a &= a - 1ull; }
+  __device__ __forceinline__ void add(int b, int on) { a |= (unsigned long long)(on & 1) << b; }
+  __device__ __forceinline__ void store(uint32_t* g) const { g[0] = (uint32_t)a; g[1] = (uint32_t)(a >> 32); }
+  __device__ __forceinline__ int count() const { return __builtin_popcountll(a); }
+};
+template <> struct OffsetSet<4> {
+  unsigned long long lo, hi;
+  __device__ __forceinline__ static OffsetSet load(const uint32_t* g) {
+    return {(unsigned long long)g[0] | ((unsigned long long)g[1] << 32),
+            (unsigned long long)g[2] | ((unsigned long long)g[3] << 32)};
+  }
+  __device__ __forceinline__ static OffsetSet none() { return {0ull, 0ull}; }
+  __device__ __forceinline__ bool any() const { return (lo | hi) != 0ull; }
+  __device__ __forceinline__ int lowest() const {
+    return lo != 0ull ? __builtin_ctzll(lo) : 64 + __builtin_ctzll(hi);
+  }
+  __device__ __forceinline__ void drop() {
+    if (lo != 0ull) lo &= lo - 1ull; else hi &= hi - 1ull;
+  }
+  __device__ __forceinline__ void add(int b, int on) {
+    const unsigned long long v = (unsigned long long)(on & 1) << (b & 63);
+    if (b < 64) lo |= v; else hi |= v;
+  }
+  __device__ __forceinline__ void store(uint32_t* g) const {
+    g[0] = (uint32_t)lo; g[1] = (uint32_t)(lo >> 32); g[2] = (uint32_t)hi; g[3] = (uint32_t)(hi >> 32);
+  }
+  __device__ __forceinline__ int count() const { return __builtin_popcountll(lo) + __builtin_popcountll(hi); }
+};
+
 // Symmetric sweep: every unordered pair {i, j} of an env is examined once, by the
 // drone whose index d satisfies j = d + k (mod N), 1 <= k <= N/2.
 //   stage G  (packed fp32, all offsets): possibly in range;
@@ -302,28 +352,29 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
               taz = {2.f * maz, 2.f * maz};
     const int fr = far ? 1 : 0;
-    constexpr int CW = NW == 1 ? 1 : 2;  // words per candidate loop
+#ifndef RVO3D_X1_CW
+#define RVO3D_X1_CW 4
+#endif
+    // words per candidate loop: a lane's whole set in one loop up to 128 offsets (256 drones)
+    constexpr int CW = NW < RVO3D_X1_CW ? NW : RVO3D_X1_CW;
 #pragma unroll
     for (int w = 0; w < NW / CW; ++w) {
-      typedef typename std::conditional<CW == 1, uint32_t, unsigned long long>::type cand_t;
-      cand_t cand = CW == 1 ? (cand_t)gw[0]
-                            : (cand_t)((unsigned long long)gw[CW * w] |
-                                       ((unsigned long long)gw[CW * w + (CW - 1)] << 32));
-      if (RVO3D_ABLATED(64)) cand = 0;
-      cand_t keep = 0;  // candidates with somebody possibly approaching (ROWS: filed for the next sweep A)
+      OffsetSet<CW> cand = OffsetSet<CW>::load(gw + CW * w);
+      if (RVO3D_ABLATED(64)) cand = OffsetSet<CW>::none();
+      OffsetSet<CW> keep = OffsetSet<CW>::none();  // candidates with somebody possibly approaching (ROWS: filed for the next sweep A)
 #ifdef RVO3D_DIAG
       if (P.dbg && ROWS) {  // diagnostics build: X1 candidates of this workgroup in the rows sweep (sum, max per lane)
-        const int c = CW == 1 ? __builtin_popcount((uint32_t)cand) : __builtin_popcountll(cand);
+        const int c = cand.count();
         atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + 24], (unsigned long long)c);
         atomicMax(&P.dbg[(size_t)blockIdx.x * 32 + 25], (unsigned long long)c);
       }
 #endif
-      while (cand) {
-        const int kb0 = CW == 1 ? __builtin_ctz((uint32_t)cand) : __builtin_ctzll(cand);
-        cand &= cand - 1;
-        const bool two = cand != 0;
-        const int kb1 = two ? (CW == 1 ? __builtin_ctz((uint32_t)cand) : __builtin_ctzll(cand)) : kb0;
-        cand &= cand - 1;
+      while (cand.any()) {
+        const int kb0 = cand.lowest();
+        cand.drop();
+        const bool two = cand.any();
+        const int kb1 = two ? cand.lowest() : kb0;
+        cand.drop();  // (of an empty set: still empty)
         const int off0 = 32 * CW * w + kb0 + 1, off1 = 32 * CW * w + kb1 + 1;
         const int oa = o0 + off0, ob = o0 + off1;
         int jd0 = d + off0, jd1 = d + off1;
@@ -392,7 +443,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
           const int oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                   \
           pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
           pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
-          if (ROWS) keep |= (cand_t)((fr | ai | aj) & 1) << kbit;                             \
+          if (ROWS) keep.add(kbit, fr | ai | aj);                                             \
         }
         bool pi0, pj0, pi1, pj1;
         {
@@ -418,10 +469,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
       // pairs in which somebody is possibly approaching: "approaching" does not depend on the
       // action, and sweep A (no touch test) asks nothing of the others - about half of the in-range
       // pairs drop out of its X1.
-      if (ROWS) {
-        if (CW == 1) gw[0] = (uint32_t)keep;
-        else { gw[CW * w] = (uint32_t)keep; gw[CW * w + (CW - 1)] = (uint32_t)((unsigned long long)keep >> 32); }
-      }
+      if (ROWS) keep.store(gw + CW * w);
     }
   }
   if (ROWS && !TOUCH) RVO3D_STAMP(12);
