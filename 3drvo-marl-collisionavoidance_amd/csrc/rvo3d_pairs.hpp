@@ -253,6 +253,67 @@ __device__ __forceinline__ uint32_t gate_word(const Params& P, const Lds& L, int
   return mr;
 }
 
+// Stage G for workgroups of exactly 64 NW drones (the compile-time 128 / 256 kernels): a drone's
+// 32 NW offsets are NW words, and word s of drone e is computed by lane e + 32 s, which tests ITS
+// 32 nearest followers (slots d + 1 .. d + 32) against NW "own" drones d, d - 32, d - 64, ... at
+// once.  Every neighbour record is read from LDS once per lane instead of once per (lane, word):
+// stage G at 256 drones was bound by LDS bandwidth (3 x 8 B per lane and two offsets, 16 waves per
+// CU: 12 of every 32 cycles per SIMD, four SIMDs on one LDS), not by its arithmetic - which is
+// the same as gate_word's, bit for bit.  The words travel to their owners through the request-mask
+// slots (u64: possibly in range | possibly touching << 32); the caller synchronises.
+#ifndef RVO3D_GS_UNROLL
+#define RVO3D_GS_UNROLL 4
+#endif
+template <int NW, bool TOUCH, bool UNIFORM_R>
+__device__ __forceinline__ void gate_words_shared(const Params& P, const Lds& L, int d) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int N = 64 * NW;
+  const v2f tn = {P.t10n, P.t10n};
+  v2f ox[NW], oy[NW], oz[NW], orr[NW], rcu[NW];
+  uint32_t mr[NW], mt[NW];
+  int own[NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    int e = d - 32 * s;
+    if (e < 0) e += N;
+    own[s] = e;
+    const float x = L.w[WX][e], y = L.w[WY][e], z = L.w[WZ][e], r = L.w[WR][e];
+    ox[s] = (v2f){x, x}; oy[s] = (v2f){y, y}; oz[s] = (v2f){z, z}; orr[s] = (v2f){r, r};
+    const v2f ru = orr[s] + orr[s];
+    rcu[s] = __builtin_elementwise_fma(ru * ru, (v2f){1.00001f, 1.00001f}, (v2f){P.bandn, P.bandn});
+    mr[s] = 0u; mt[s] = 0u;
+  }
+#pragma unroll RVO3D_GS_UNROLL
+  for (int b = 30; b >= 0; b -= 2) {
+    const int o = d + b + 1;
+    const v2f X = {L.w[WX][o], L.w[WX][o + 1]}, Y = {L.w[WY][o], L.w[WY][o + 1]},
+              Z = {L.w[WZ][o], L.w[WZ][o + 1]};
+    v2f R = {0.f, 0.f};
+    if (TOUCH && !UNIFORM_R) R = (v2f){L.w[WR][o], L.w[WR][o + 1]};
+#pragma unroll
+    for (int s = 0; s < NW; ++s) {
+      const v2f dx = X - ox[s], dy = Y - oy[s], dz = Z - oz[s];
+      v2f acc = __builtin_elementwise_fma(dx, dx, tn);
+      acc = __builtin_elementwise_fma(dy, dy, acc);
+      acc = __builtin_elementwise_fma(dz, dz, acc);
+      mr[s] = shift_in_sign(shift_in_sign(mr[s], acc.y), acc.x);
+      if (TOUCH) {
+        v2f rc = rcu[s];
+        if (!UNIFORM_R) {
+          const v2f rs = R + orr[s];
+          rc = __builtin_elementwise_fma(rs * rs, (v2f){1.00001f, 1.00001f}, (v2f){P.bandn, P.bandn});
+        }
+        const v2f at = acc - rc;
+        mt[s] = shift_in_sign(shift_in_sign(mt[s], at.y), at.x);
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NW; ++s)
+    L.mask2[own[s] * NW + s] =
+        (unsigned long long)mr[s] | ((unsigned long long)(TOUCH ? (mt[s] & mr[s]) : 0u) << 32);
+}
+
 // The offsets one X1 loop walks, as a bit set of CW words (32 offsets each): pop-lowest, test, set.
 template <int CW> struct OffsetSet;
 template <> struct OffsetSet<1> {
@@ -312,7 +373,7 @@ template <> struct OffsetSet<4> {
 //   stage X2 (fp64, requested pairs only): pair_eval.
 // G and X1 only ever drop pairs that pair_eval would return "nothing" for.
 // NW = ceil(N / 64): words per request mask (64 drones) and per offset mask (32 offsets).
-template <int NW, bool ROWS, bool TOUCH, bool TRAIN>
+template <int NW, bool ROWS, bool TOUCH, bool TRAIN, bool GSHARE = false>
 __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane, int el, int d,
                                          int g, bool active, const Drone& S, const double a[3],
                                          bool zero_act, bool& flag, double& tmin,
@@ -321,6 +382,24 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
   tmin = __builtin_inf();
   int kept = 0;
   const int N = P.N, H = N >> 1;
+  if (GSHARE && !have_gw) {
+    // (have_gw is uniform over the workgroup: one env, and P.g_cached / "the env reset somebody")
+    // stage G first, shared between the lanes (gate_words_shared); the words arrive in the
+    // owners' request-mask slots, which the owners then clear for stage X1
+    // (the last readers of the request masks - the exact stage of the previous sweep, each lane its
+    // own slots - are at least one barrier behind: every caller stages or integrates in between)
+    const bool far = L.far[el] != 0;
+    if (active && !far) gate_words_shared<NW, false, false>(P, L, d);
+    __syncthreads();
+    if (active) {
+      uint32_t valid[NW];
+      valid_offsets<NW>(P.N, d, valid);
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        gw[w] = far ? valid[w] : ((uint32_t)L.mask2[lane * NW + w] & valid[w]);
+    }
+    have_gw = true;
+  }
 #pragma unroll
   for (int w = 0; w < NW; ++w) L.mask2[lane * NW + w] = 0ull;
   __syncthreads();
@@ -511,11 +590,28 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 // position, with dis <= r + mr (env_train) - for every drone of the env.  Each
 // unordered pair is tested once; the fp32 stage only selects pairs that are possibly
 // touching, the decision itself is fp64.
-template <int NW, bool TRAIN>
+template <int NW, bool TRAIN, bool GSHARE = false>
 __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int lane, int el,
                                             int d, bool active, const Drone& S,
                                             uint32_t gw[NW]) {
   const int N = P.N, H = N >> 1;
+  uint32_t touchw[NW];  // GSHARE: the possibly-touching words, from gate_words_shared
+  if (GSHARE) {
+    // (the request masks were last read by sweep A's exact stage, before the integrate barriers)
+    const bool far = L.far[el] != 0;  // uniform over the workgroup (one env)
+    if (active && !far) {
+      if (P.uniform_rp) gate_words_shared<NW, true, true>(P, L, d);
+      else gate_words_shared<NW, true, false>(P, L, d);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const unsigned long long v = L.mask2[lane * NW + w];
+      gw[w] = (uint32_t)v;
+      touchw[w] = (uint32_t)(v >> 32);
+      if (w) L.mask2[lane * NW + w] = 0ull;
+    }
+  }
   L.mask2[lane * NW] = 0ull;
   __syncthreads();
   bool coll = false;
@@ -530,12 +626,17 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
       // one pass over the offsets: possibly touching (cand) and possibly in range (gw, the
       // stage-G words of this post-move state for the rows sweep that follows)
       uint32_t cand = valid[w];
-      gw[w] = valid[w];
-      if (!far) {
-        uint32_t rng;
-        cand = (P.uniform_rp ? gate_word<true, true>(P, L, o0, w, H, mex, mey, mez, mer, &rng)
-                             : gate_word<true, false>(P, L, o0, w, H, mex, mey, mez, mer, &rng)) & valid[w];
-        gw[w] = rng & valid[w];
+      if (GSHARE) {
+        if (!far) cand = touchw[w] & valid[w];
+        gw[w] = far ? valid[w] : (gw[w] & valid[w]);
+      } else {
+        gw[w] = valid[w];
+        if (!far) {
+          uint32_t rng;
+          cand = (P.uniform_rp ? gate_word<true, true>(P, L, o0, w, H, mex, mey, mez, mer, &rng)
+                               : gate_word<true, false>(P, L, o0, w, H, mex, mey, mez, mer, &rng)) & valid[w];
+          gw[w] = rng & valid[w];
+        }
       }
       while (cand) {  // exact decision, both drones of the pair
         const int kb = __builtin_ctz(cand);

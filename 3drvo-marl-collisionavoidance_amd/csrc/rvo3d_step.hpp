@@ -438,6 +438,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   const int lbase = el * N;
   const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
   constexpr bool LITE = (MODE == kStepAutoReset);
+  // stage G shared between the lanes (gate_words_shared): workgroups of exactly 64 NW drones
+  constexpr bool GSH = NW > 1 && NFIX == 64 * NW;
 
   // Register discipline: values are loaded right before the phase that needs them and
   // stored as soon as they are final, so that across the sweeps little more than the
@@ -517,7 +519,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       if (dev > max_dev) max_dev = dev;
     }
     uint32_t gw[NW];
-    const int kept = sweep_env<NW, true, true, TRAIN>(P, L, tid, el, d, g, active, S, zero3, true, flag,
+    const int kept = sweep_env<NW, true, true, TRAIN, GSH>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision, gw, false);
     if (active) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
 #pragma unroll
     for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
   }
-  sweep_env<NW, false, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(1), S, az, false, flag,
+  sweep_env<NW, false, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(1), S, az, false, flag,
                               tmin, collision, gw, have_gw);
   // ---- everything else about this drone arrives in ONE batch of loads now (none of the
   //      addresses depends on a loaded value), then: drone.dronestate on the pre-move state
@@ -676,9 +678,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // state with the action, or on the post-reset state with action 0.
   int kept = 0;
   if (LITE) {
-    if (collide_env<NW, TRAIN>(P, L, tid, el, d, active && !RVO3D_ABLATED(2), S, gw)) collision = true;
+    if (collide_env<NW, TRAIN, GSH>(P, L, tid, el, d, active && !RVO3D_ABLATED(2), S, gw)) collision = true;
   } else {
-    kept = sweep_env<NW, true, true, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(2), S, az, false,
+    kept = sweep_env<NW, true, true, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(2), S, az, false,
                                      flag, tmin, collision, gw, false);
   }
   bool do_reset = false;
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
     // two-phase row writer: the zeros of every block without proprio bytes leave now
     if (two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
-    kept = sweep_env<NW, true, false, TRAIN>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
+    kept = sweep_env<NW, true, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);

@@ -334,7 +334,7 @@ def test_cfg5_shape_256_drones_50_buildings():
     assert st["done"] > 0, st
 
 
-@pytest.mark.parametrize("N,E,nm", [(3, 5, 10), (12, 33, 2), (24, 7, 0), (100, 3, 10), (300, 2, 4)])
+@pytest.mark.parametrize("N,E,nm", [(3, 5, 10), (12, 33, 2), (24, 7, 0), (100, 3, 10), (128, 5, 3), (300, 2, 4)])
 def test_ragged_sizes(N, E, nm):
     """N not a power of two, E not a multiple of envs-per-block, nm = 0, N > 256."""
     L = 6 + 2 * int(np.sqrt(N))
@@ -350,7 +350,7 @@ def test_dense_small_nm_truncation():
     assert st["vo_rows"] > 500, st
 
 
-@pytest.mark.parametrize("N,E", [(16, 64), (64, 12), (100, 3)])
+@pytest.mark.parametrize("N,E", [(16, 64), (64, 12), (100, 3), (128, 3), (256, 2)])
 def test_per_drone_radius_and_priority(N, E):
     """radius / priority arrays that differ from drone to drone (the step then reads them per
     drone instead of taking the one value from its argument block; get_PAA's pr = pra / (pra + prb)
@@ -399,7 +399,7 @@ def test_cfg2_velocity_like_actions():
     assert st["vo_rows"] > 50, st
 
 
-@pytest.mark.parametrize("N,E", [(16, 12), (100, 3)])
+@pytest.mark.parametrize("N,E", [(16, 12), (100, 3), (128, 3), (256, 2)])
 def test_drones_far_outside_the_map_bypass_the_fp32_filters(N, E):
     """The fp32 stages (G, X1) assume centred coordinates within `cmax` of the map; an env with a
     drone beyond that (here: clusters teleported hundreds of metres away, close enough to each
