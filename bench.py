@@ -279,7 +279,8 @@ def main():
             "config": {"workload": f"BASELINE config 3 env.step: {N} drones x {E} envs per GPU, "
                                    f"nm={nm}, {nb} buildings, map {args.map}, fused step"
                                    f"{'+auto-reset' if autoreset else ''}, f32 actions in HBM",
-                       "envs_per_gpu": E, "drones": N, "launch": env.launch_info(), "diag_build": diag,
+                       "envs_per_gpu": E, "drones": N, "launch": env.launch_info(),
+                       "untimed_steps_before_warmup": args.prewarm, "diag_build": diag,
                        "ablate": int(os.environ.get("RVO3D_ABLATE", "0")) if diag else 0,
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
