@@ -48,3 +48,21 @@ def test_eval_mode_scenario_and_call_vectors_regenerate():
     # the generator draws kind by kind: the first 8 geometries of kind 0 are the fixture's first 16 rows
     for k in ("self8", "other8", "action", "obs9", "flag", "raises"):
         assert _same(calls[k][:16], old[k][:16]), k
+
+
+def test_wide_scenarios_regenerate():
+    """oracle/gen_golden_wide.py: one line-up (k > nm truncation at 64 drones) and the 96-drone
+    trainer scenario, a few seconds of reference time each."""
+    import gen_golden as gg
+    import gen_golden_wide as gw
+    want = {"wide12_n64_lineup_nm3", "wide4_n96_trainer"}
+    seen = 0
+    for name, world, actor, T, seed, kw in gw.wide_scenarios():
+        if name not in want:
+            continue
+        fx = gg.run_scenario(world, actor, T, seed, **kw)
+        old = load(os.path.join(GOLDEN, name + ".npz"))
+        for k, v in fx.items():
+            assert _same(v, old[k]), (name, k)
+        seen += 1
+    assert seen == len(want)
