@@ -423,8 +423,8 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     }
     if (ROWS && !TOUCH) RVO3D_STAMP(11);
     // stage X1, two candidate pairs per trip in packed fp32 (a lane with an odd count repeats
-    // its last candidate: the requests are idempotent ORs).  Workgroups of several waves walk
-    // 64 offsets per loop (two words): fewer, fuller trips than one loop per word.
+    // its last candidate: the requests are idempotent ORs).  One loop walks a lane's whole
+    // candidate set up to 128 offsets (OffsetSet): fewer, fuller trips than one loop per word.
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
     const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};

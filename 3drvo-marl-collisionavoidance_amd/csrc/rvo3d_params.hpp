@@ -36,7 +36,8 @@ struct Cold {
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)
   // building grid over the map's xy plane (rvo3d_load_world): cell (ix, iy) lists every
-  // building whose 5 m gate circle reaches the cell, kBgridK + 1 u16 per cell = count, indices;
+  // building a drone inside the cell could hit (within min(5 m gate, largest drone radius +
+  // building radius) of the cell), kBgridK + 1 u16 per cell = count, indices;
   // count 0xffff = more than kBgridK: test all.  bgx == 0: no grid.
   const uint16_t* bgrid;
   int bgx, bgy;
