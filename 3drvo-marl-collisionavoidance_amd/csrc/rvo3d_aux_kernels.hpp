@@ -89,7 +89,7 @@ __device__ __forceinline__ double arange_at(double lo, int k) {  // numpy fills 
   return k == 0 ? lo : (k == 1 ? next : lo + k * (next - lo));
 }
 
-__global__ void rvo_vel_kernel(const Params P, const RvoVelArgs A, double* out) {
+__global__ void __launch_bounds__(512) rvo_vel_kernel(const Params P, const RvoVelArgs A, double* out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = P.N, d = threadIdx.x, e = blockIdx.x;
   const int T = blockDim.x;
@@ -120,10 +120,14 @@ __global__ void rvo_vel_kernel(const Params P, const RvoVelArgs A, double* out) 
   }
   const int C = cnt[0] * cnt[1] * cnt[2];  // candidate c = (ix * cnt1 + iy) * cnt2 + iz
   unsigned long long live = 0ull, inside = 0ull;
-  for (int c = 0; c < C; ++c) {
-    const int iz = c % cnt[2], iy = (c / cnt[2]) % cnt[1], ix = c / (cnt[2] * cnt[1]);
-    const double vx = arange_at(lo[0], ix), vy = arange_at(lo[1], iy), vz = arange_at(lo[2], iz);
-    if (!(__builtin_sqrt(sq(vx) + sq(vy) + sq(vz)) < 0.3)) live |= 1ull << c;
+  // candidate c = (ix * cnt1 + iy) * cnt2 + iz: nested loops, no division by the runtime counts
+  {
+    int c = 0;
+    for (int ix = 0; ix < cnt[0]; ++ix)
+      for (int iy = 0; iy < cnt[1]; ++iy)
+        for (int iz = 0; iz < cnt[2]; ++iz, ++c)
+          if (!(__builtin_sqrt(sq(arange_at(lo[0], ix)) + sq(arange_at(lo[1], iy)) + sq(arange_at(lo[2], iz))) < 0.3))
+            live |= 1ull << c;
   }
   double tc_min = __builtin_inf();
   for (int j = 0; j < N; ++j) {
@@ -156,36 +160,63 @@ __global__ void rvo_vel_kernel(const Params P, const RvoVelArgs A, double* out) 
     const double ax = bx - S.x, ay = by - S.y, az = bz - S.z;  // get_rvo_array
     const double nab = norm3b(ax, ay, az);
     const double q = (S.r + br) / nab;
-    const double alpha = (q <= 1.0) ? py_round2_c(asin(q)) / 100.0 : 1.57;  // get_alpha
+    const double alpha_c = (q <= 1.0) ? py_round2_c(asin(q)) : 157.0;       // get_alpha, alpha = alpha_c / 100
+    const double alpha = alpha_c / 100.0;
     const double pr = S.prio / (S.prio + bprio);                            // get_PAA
     const double pax = pr * (2 * S.x + (S.vx + bvx) * 1), pay = pr * (2 * S.y + (S.vy + bvy) * 1),
                  paz = pr * (2 * S.z + (S.vz + bvz) * 1);
-    for (int c = 0; c < C; ++c) {  // vo_out2 (:103-117)
-      if (!((live >> c) & 1ull)) continue;
-      const int iz = c % cnt[2], iy = (c / cnt[2]) % cnt[1], ix = c / (cnt[2] * cnt[1]);
-      const double wx = (S.x + arange_at(lo[0], ix) * 1) - pax,
-                   wy = (S.y + arange_at(lo[1], iy) * 1) - pay,
-                   wz = (S.z + arange_at(lo[2], iz) * 1) - paz;
-      const double AB = nab * norm3b(wx, wy, wz);
-      const double cs = (AB != 0) ? dot3b(ax, ay, az, wx, wy, wz) / AB : 0.0;  // get_beta
-      const double beta = __builtin_rint(acos(cs) * 100.0) / 100.0;
-      if (alpha > beta) inside |= 1ull << c;
+    // alpha > beta with beta = rint(acos(cs) * 100) / 100 holds iff rint(acos(cs) * 100) <= alpha_c - 1,
+    // i.e. - away from the rounding tie - iff acos(cs) * 100 < alpha_c - 0.5, iff cs > cos((alpha_c - 0.5) / 100)
+    // =: thr (> 0 for every alpha_c <= 157).  One cos per neighbour decides the candidates whose
+    // cs^2 = dot |dot| / (|a|^2 |w|^2) is further than 1e-9 (relative) from thr^2 and from 1 (cs = 1 + ulp makes
+    // arccos NaN: outside); the rest take the reference's own sequence.  alpha_c < 1: never inside.
+    const double thr = cos((alpha_c - 0.5) / 100.0);
+    const double thr2n = thr * thr * dot3b(ax, ay, az, ax, ay, az);
+    const double nab2 = dot3b(ax, ay, az, ax, ay, az);
+    if (alpha_c >= 1.0) {  // vo_out2 (:103-117)
+      int c = 0;
+      for (int ix = 0; ix < cnt[0]; ++ix) {
+        const double wx = (S.x + arange_at(lo[0], ix) * 1) - pax;
+        for (int iy = 0; iy < cnt[1]; ++iy) {
+          const double wy = (S.y + arange_at(lo[1], iy) * 1) - pay;
+          for (int iz = 0; iz < cnt[2]; ++iz, ++c) {
+            if (!((live >> c) & 1ull)) continue;
+            const double wz = (S.z + arange_at(lo[2], iz) * 1) - paz;
+            const double dotp = dot3b(ax, ay, az, wx, wy, wz), w2 = dot3b(wx, wy, wz, wx, wy, wz);
+            const double lhs = dotp * __builtin_fabs(dotp), rhs = thr2n * w2, one = nab2 * w2;
+            bool in;
+            if (lhs < rhs * (1.0 - 1e-9)) in = false;                          // surely cs < thr (or dot <= 0)
+            else if (lhs > rhs * (1.0 + 1e-9) && lhs < one * (1.0 - 1e-9)) in = true;  // surely thr < cs < 1
+            else {
+              const double AB = nab * norm3b(wx, wy, wz);
+              const double cs = (AB != 0) ? dotp / AB : 0.0;  // get_beta
+              const double beta = __builtin_rint(acos(cs) * 100.0) / 100.0;
+              in = alpha > beta;
+            }
+            if (in) inside |= 1ull << c;
+          }
+        }
+      }
     }
   }
   const double tc_inv = (tc_min == 0) ? __builtin_inf() : 1.0 / tc_min;
   bool have_out = false, have_in = false;
   double best_out = 0, best_in = 0, so[3] = {0, 0, 0}, si[3] = {0, 0, 0};
-  for (int c = 0; c < C; ++c) {  // vel_select (:119-124): Python min keeps the first minimum
-    if (!((live >> c) & 1ull)) continue;
-    const int iz = c % cnt[2], iy = (c / cnt[2]) % cnt[1], ix = c / (cnt[2] * cnt[1]);
-    const double vx = arange_at(lo[0], ix), vy = arange_at(lo[1], iy), vz = arange_at(lo[2], iz);
-    const double dd = __builtin_sqrt(sq(des[0] - vx) + sq(des[1] - vy) + sq(des[2] - vz));
-    if (!((inside >> c) & 1ull)) {
-      if (!have_out || dd < best_out) { best_out = dd; so[0] = vx; so[1] = vy; so[2] = vz; have_out = true; }
-    } else {
-      const double pen = 1 * tc_inv + dd;
-      if (!have_in || pen < best_in) { best_in = pen; si[0] = vx; si[1] = vy; si[2] = vz; have_in = true; }
-    }
+  {  // vel_select (:119-124): Python min keeps the first minimum
+    int c = 0;
+    for (int ix = 0; ix < cnt[0]; ++ix)
+      for (int iy = 0; iy < cnt[1]; ++iy)
+        for (int iz = 0; iz < cnt[2]; ++iz, ++c) {
+          if (!((live >> c) & 1ull)) continue;
+          const double vx = arange_at(lo[0], ix), vy = arange_at(lo[1], iy), vz = arange_at(lo[2], iz);
+          const double dd = __builtin_sqrt(sq(des[0] - vx) + sq(des[1] - vy) + sq(des[2] - vz));
+          if (!((inside >> c) & 1ull)) {
+            if (!have_out || dd < best_out) { best_out = dd; so[0] = vx; so[1] = vy; so[2] = vz; have_out = true; }
+          } else {
+            const double pen = 1 * tc_inv + dd;
+            if (!have_in || pen < best_in) { best_in = pen; si[0] = vx; si[1] = vy; si[2] = vz; have_in = true; }
+          }
+        }
   }
   double* o = out + 3 * (size_t)g;
   if (have_out) { o[0] = so[0]; o[1] = so[1]; o[2] = so[2]; }
