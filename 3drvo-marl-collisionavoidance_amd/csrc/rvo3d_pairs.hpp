@@ -442,7 +442,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
       if (RVO3D_ABLATED(64)) cand = OffsetSet<CW>::none();
       OffsetSet<CW> keep = OffsetSet<CW>::none();  // candidates with somebody possibly approaching (ROWS: filed for the next sweep A)
 #ifdef RVO3D_DIAG
-      if (P.dbg && ROWS) {  // diagnostics build: X1 candidates of this workgroup in the rows sweep (sum, max per lane)
+      if (P.dbg && ROWS && RVO3D_ABLATED(128)) {  // diagnostics build, RVO3D_ABLATE bit 128 = count: X1 candidates of this workgroup in the rows sweep (sum, max per lane)
         const int c = cand.count();
         atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + 24], (unsigned long long)c);
         atomicMax(&P.dbg[(size_t)blockIdx.x * 32 + 25], (unsigned long long)c);
@@ -555,7 +555,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
   if (!ROWS) RVO3D_STAMP(14);
   __syncthreads();
 #ifdef RVO3D_DIAG
-  if (P.dbg && active) {  // diagnostics build: X2 requests of this workgroup (sum, max per lane)
+  if (P.dbg && active && RVO3D_ABLATED(128)) {  // diagnostics build, bit 128 = count: X2 requests of this workgroup (sum, max per lane)
     int c = 0;
     for (int w = 0; w < NW; ++w) c += __builtin_popcountll(L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull));
     atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + (ROWS ? 22 : 20)], (unsigned long long)c);

@@ -755,8 +755,10 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       have_gw2 = true;
     }
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
+    RVO3D_STAMP(26);
     // two-phase row writer: the zeros of every block without proprio bytes leave now
     if (two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
+    RVO3D_STAMP(27);
     kept = sweep_env<NW, true, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       env_reset, flag, tmin, c2, gw, have_gw2);
   }

@@ -1,5 +1,7 @@
 """Diagnostic: where does a wave spend its life?  Attaches the stamp buffer
-(rvo3d_debug_stamps) and prints per-phase mean cycles over all workgroups."""
+(rvo3d_debug_stamps) and prints per-phase mean cycles over all workgroups.
+RVO3D_ABLATE=128 also counts the X1 candidates / X2 requests (global atomics inside the sweeps:
+the phase times of such a run are inflated - use one run for the times, another for the counts)."""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -41,6 +43,9 @@ if s[:, 24:26].any():
     T_ = env.launch_info()["threads"]
     print(f"  X1 candidates per lane in the rows sweep: mean {s[:, 24].mean() / T_:.3f}; busiest lane of a workgroup: mean {s[:, 25].mean():.2f} "
           f"p95 {np.percentile(s[:, 25], 95):.0f} (trips = half of it)")
+if s[:, 26:28].any():
+    print(f"  before the rows sweep: re-gate after resets {(s[:, 26] - s[:, 6]).mean():8.0f}  early zero blocks {(s[:, 27] - s[:, 26]).mean():8.0f}  "
+          f"sweep entry (masks, own record) {(s[:, 10] - s[:, 27]).mean():8.0f}")
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
 
