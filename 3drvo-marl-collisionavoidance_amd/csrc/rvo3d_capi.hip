@@ -284,6 +284,28 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     C.zf_magic = m;
   }
   C.zf_q = (P.W & 1) == 0 ? (uint32_t)(P.W / 2) : 0u;  // row bytes / 8: the 16-B row writer applies
+  // early_zero_blocks: which of its trips a thread quad stores in depends on W and the quad only
+  C.zf_iters = 0;
+  std::memset(C.zmask, 0, sizeof C.zmask);
+  {
+    const uint32_t rb = 4u * (uint32_t)P.W;
+    const uint32_t rows_full = (uint32_t)epb * (uint32_t)N, nwv = (uint32_t)threads / 64u;
+    const uint32_t nblk = rows_full * rb >> 6;
+    const uint32_t iters = (nblk + 16u * nwv - 1u) / (16u * nwv);
+    if (C.zf_q != 0 && P.W >= 48 && (rows_full & 7u) == 0 && iters <= 32u) {
+      for (uint32_t tq = 0; tq < (uint32_t)threads / 4u; ++tq) {
+        uint32_t m = 0;
+        for (uint32_t i = 0; i < iters; ++i) {
+          const uint32_t blk = tq + 16u * nwv * i;  // tq = wave * 16 + (lane / 4)
+          if (blk >= nblk) break;
+          const uint32_t o = (blk * 64u) % rb;
+          if (o >= 48u && o + 64u <= rb) m |= 1u << i;
+        }
+        C.zmask[tq] = m;
+      }
+      C.zf_iters = (int)iters;
+    }
+  }
   h->threads = threads;
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;

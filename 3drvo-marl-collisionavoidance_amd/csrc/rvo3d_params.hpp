@@ -32,6 +32,10 @@ struct Cold {
   uint32_t zf_div;    // zero-fill: units (8 B or 4 B) per row of the VO region
   uint32_t zf_magic;  // ceil(2^32 / zf_div)
   uint32_t zf_q;      // 16-B row writer (W even): row bytes / 8, else 0
+  // two-phase row writer, part 1: for thread quad tq = tid / 4, bit i = "the 64-B block this quad
+  // meets in trip i holds no proprio byte" (a full workgroup's rows; zf_iters trips, 0: no table)
+  int zf_iters;
+  uint32_t zmask[128];
   int nb;
   const double* bld;       // [nb][4]
   const double* pow95;     // [P]   0.95 ** k, host libm (ir_gym.py:283)

@@ -192,35 +192,34 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
 // the zeros afterwards (after s_waitcnt vmcnt(0): the zeros of its own wave have landed; workgroups
 // of several waves drain before the sweep's second barrier).  The late blocks are written after the
 // sweep as 128-B windows, one per row, from the proprio staged in LDS (part 2 below).
+// Full workgroups only (the host tabulates the block pattern of a full workgroup, zf_iters > 0:
+// W even, 48 <= W <= 128, rows per workgroup a multiple of 8); the last, partial workgroup of a
+// launch and other widths take the row-pair writer.
 __device__ __forceinline__ bool two_phase_rows(const Params& P, int row0, int nrows) {
-  return P.zf16 && P.W >= 48 && ((row0 | nrows) & 7) == 0;
+  return P.zf16 && P.cold().zf_iters > 0 && nrows == P.epb * P.N && (row0 & 7) == 0;
 }
 
 // part 1: zeros of every 64-B block that holds no proprio byte.  One wave-instruction = 16 blocks
-// (1 KB, whole lines); the block's offset inside its row advances by a constant per trip.
+// (1 KB, whole lines).
 template <int NW>
 __device__ __forceinline__ void early_zero_blocks(const Params& P, const Lds& L, int tid, int row0,
                                                   int nrows) {
   const uint32_t rb = 4u * (uint32_t)P.W;  // row bytes (a multiple of 8)
   const int ln = tid & 63, wv = tid >> 6;
   const int nwv = NW == 1 ? 1 : (L.T >> 6);
-  const uint32_t nblk = (uint32_t)nrows * rb >> 6;
+  (void)nrows;  // a full workgroup (two_phase_rows)
   char* const base = reinterpret_cast<char*>(P.obs) + (size_t)row0 * rb;
-  uint32_t blk = (uint32_t)wv * 16u + ((uint32_t)ln >> 2);
-  uint32_t o = (blk * 64u) % rb;                           // offset of the block's start in its row
-  const uint32_t ostep = (1024u * (uint32_t)nwv) % rb;     // 16 * nwv blocks further
-  const uint32_t sub = 16u * ((uint32_t)ln & 3u);
+  const uint32_t blk = (uint32_t)wv * 16u + ((uint32_t)ln >> 2);
   typedef float v4f __attribute__((ext_vector_type(4)));
-  for (; blk < nblk; blk += 16u * (uint32_t)nwv) {
-    // no proprio of its own row (o >= 48) and none of the next row (o + 64 <= rb)
-    // streaming stores: whole 64-B blocks nobody reads back (-1 %; the windows of part 2, whose
-    // lines are shared with the kept rows, are faster as ordinary stores)
-    if (o >= 48u && o + 64u <= rb)
-      __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f},
-                                  reinterpret_cast<v4f*>(base + (size_t)blk * 64u + sub));
-    o += ostep;
-    if (o >= rb) o -= rb;
-  }
+  // which trips store is a property of the thread quad, tabulated by the host (rvo3d_create): no
+  // per-trip offset arithmetic.  Streaming stores: whole 64-B blocks nobody reads back (-1 %; the
+  // windows of part 2, whose lines are shared with the kept rows, are faster as ordinary stores)
+  const int iters = P.cold().zf_iters;
+  uint32_t m = P.cold().zmask[tid >> 2];
+  char* p = base + (size_t)blk * 64u + 16u * ((uint32_t)ln & 3u);
+  const size_t step = (size_t)1024 * (size_t)nwv;
+  for (int i = 0; i < iters; ++i, p += step, m >>= 1)
+    if (m & 1u) __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(p));
 }
 
 // part 2: per row the 128-B window that starts at the 64-B block holding the row's first byte: the
@@ -236,21 +235,27 @@ __device__ __forceinline__ void late_row_windows(const Params& P, const Lds& L, 
   const float2* pro2 = reinterpret_cast<const float2*>(L.w[0]);
   char* const base = reinterpret_cast<char*>(P.obs) + (size_t)row0 * rb;
   const int ch = ln & 7;
-  for (int r = wv * 8 + (ln >> 3); r < nrows; r += 8 * nwv) {
-    const uint32_t rs = rb * (uint32_t)r;       // row start, relative to the workgroup's range
-    const uint32_t s8 = (rs & 63u) >> 3;        // units of the window that belong to row r - 1
-    const uint32_t ws = rs & ~63u;              // window start
-    // this chunk's two units: (row, unit in that row)
-    const uint32_t ua = 2u * (uint32_t)ch, ub = ua + 1u;
-    const bool pa = ua < s8, pb = ub < s8;      // in the previous row's tail
-    const int ra = pa ? r - 1 : r, rbw = pb ? r - 1 : r;
-    const uint32_t uia = pa ? q - s8 + ua : ua - s8, uib = pb ? q - s8 + ub : ub - s8;
-    const int za = L.kept[ra], zb = L.kept[rbw];   // r - 1 >= 0 whenever pa / pb (s8 = 0 at r = 0)
-    const bool proa = uia < 6u, prob = uib < 6u;
-    const float2 da = pro2[ra * 6 + (int)(proa ? uia : 5u)], db = pro2[rbw * 6 + (int)(prob ? uib : 5u)];
+  const int r0 = wv * 8 + (ln >> 3);
+  // A trip advances every lane by 8 * nwv rows = a multiple of 64 B (W is even): where the lane's
+  // chunk sits relative to its row - which of its two 8-B units belong to the previous row's tail,
+  // which are proprio, which unit of the row they are - is the same in every trip.  Only the row
+  // itself (its kept count, its proprio floats) changes.
+  const uint32_t rs0 = rb * (uint32_t)r0;      // row start of the first trip, relative to the workgroup's range
+  const uint32_t s8 = (rs0 & 63u) >> 3;        // units of the window that belong to row r - 1
+  const uint32_t ua = 2u * (uint32_t)ch, ub = ua + 1u;
+  const bool pa = ua < s8, pb = ub < s8;       // in the previous row's tail (never in row 0: s8 = 0 there)
+  const uint32_t uia = pa ? q - s8 + ua : ua - s8, uib = pb ? q - s8 + ub : ub - s8;
+  const bool proa = uia < 6u, prob = uib < 6u;
+  const int pia = (int)(proa ? uia : 5u), pib = (int)(prob ? uib : 5u);
+  const int da_row = pa ? 1 : 0, db_row = pb ? 1 : 0;
+  char* pc = base + (rs0 & ~63u) + 16u * (uint32_t)ch;
+  const size_t step = (size_t)8 * (size_t)nwv * rb;
+  for (int r = r0; r < nrows; r += 8 * nwv, pc += step) {
+    const int ra = r - da_row, rbw = r - db_row;
+    const int za = L.kept[ra], zb = L.kept[rbw];
+    const float2 da = pro2[ra * 6 + pia], db = pro2[rbw * 6 + pib];
     const bool va = proa | (uia >= (uint32_t)za), vb = prob | (uib >= (uint32_t)zb);
     const float2 a = proa ? da : make_float2(0.f, 0.f), b = prob ? db : make_float2(0.f, 0.f);
-    char* const pc = base + ws + 16u * (uint32_t)ch;
     if (va & vb) *reinterpret_cast<float4*>(pc) = make_float4(a.x, a.y, b.x, b.y);
     if (va != vb) *reinterpret_cast<float2*>(pc + (vb ? 8 : 0)) = vb ? b : a;
   }

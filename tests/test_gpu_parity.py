@@ -334,7 +334,8 @@ def test_cfg5_shape_256_drones_50_buildings():
     assert st["done"] > 0, st
 
 
-@pytest.mark.parametrize("N,E,nm", [(3, 5, 10), (12, 33, 2), (24, 7, 0), (100, 3, 10), (128, 5, 3), (300, 2, 4)])
+@pytest.mark.parametrize("N,E,nm", [(3, 5, 10), (12, 33, 2), (24, 7, 0), (100, 3, 10), (128, 5, 3), (300, 2, 4),
+                                    (16, 6, 10), (32, 3, 10), (8, 13, 12)])
 def test_ragged_sizes(N, E, nm):
     """N not a power of two, E not a multiple of envs-per-block, nm = 0, N > 256."""
     L = 6 + 2 * int(np.sqrt(N))
