@@ -292,7 +292,8 @@ class multi_ppo:
         after.  Built on first use; zero_grad keeps the views (set_to_none=False, see _zero)."""
         if self._flat is None:
             params = list(self.ac.parameters())
-            flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+            # + one slot behind the gradients: the policy pass sends its KL estimate along
+            flat = torch.zeros(sum(p.numel() for p in params) + 1, dtype=params[0].dtype, device=params[0].device)
             off = 0
             for p in params:
                 g = flat[off:off + p.numel()].view_as(p)
@@ -308,13 +309,20 @@ class multi_ppo:
         views of the bucket (zeroed in place)."""
         opt.zero_grad(set_to_none=self._world() == 1)
 
-    def _allreduce_grads(self):
+    def _allreduce_grads(self, kl=None):
+        """ONE collective per optimizer step: the flat gradient bucket (0.7 - 2.7 MB: latency-bound on
+        xGMI), averaged over the ranks.  A policy pass gives its KL estimate a ride in the bucket's last
+        slot and gets the mean back (every rank the same value, so every rank stops at the same
+        iteration) - the separate all-reduce of one scalar it replaces cost a second latency."""
         d = self.dist
         if d is None or not d.is_initialized() or d.get_world_size() == 1:
-            return
+            return kl
         flat = self._bucket()
-        d.all_reduce(flat)  # one bucket per optimizer step (0.7 - 2.7 MB: latency-bound on xGMI)
+        if kl is not None:
+            flat[-1] = float(kl)
+        d.all_reduce(flat)
         flat /= d.get_world_size()
+        return float(flat[-1]) if kl is not None else None
 
     def _mean_over_ranks(self, x: float) -> float:
         d = self.dist
@@ -356,12 +364,17 @@ class multi_ppo:
                 mb = {k: v[idx] for k, v in data.items()}
                 self._zero(self.pi_optimizer)
                 loss_pi, pi_info = self.compute_loss_pi(mb)
-                kl = self._mean_over_ranks(pi_info["kl"])
+                kl = pi_info["kl"]
+                if self._world() > 1:
+                    # the mean KL comes back with the gradients (one collective); the check still
+                    # precedes the step - at the stopping iteration the backward pass is discarded
+                    loss_pi.backward()
+                    kl = self._allreduce_grads(kl=kl)
                 if kl > self.target_kl:  # KL check before the step
                     stop = True
                     break
-                loss_pi.backward()
-                self._allreduce_grads()
+                if self._world() == 1:
+                    loss_pi.backward()
                 torch.nn.utils.clip_grad_norm_(self.ac.parameters(), max_norm=2.0)
                 self.pi_optimizer.step()
                 pi_steps += 1
@@ -396,11 +409,14 @@ class multi_ppo:
             for i in range(self.train_pi_iters):
                 self._zero(self.pi_optimizer)
                 loss_pi, pi_info = self.compute_loss_pi(data)
-                kl = self._mean_over_ranks(pi_info["kl"])
+                kl = pi_info["kl"]
+                if self._world() > 1:  # as in the pooled update: the mean KL rides in the gradient bucket
+                    loss_pi.backward()
+                    kl = self._allreduce_grads(kl=kl)
                 if kl > self.target_kl:
                     break
-                loss_pi.backward()
-                self._allreduce_grads()
+                if self._world() == 1:
+                    loss_pi.backward()
                 torch.nn.utils.clip_grad_norm_(self.ac.parameters(), max_norm=2.0)
                 self.pi_optimizer.step()
                 steps += 1

@@ -106,14 +106,21 @@ class GradBucket:
         self.tr = multi_ppo(env, self.ac, steps_per_epoch=1, dist=dist)
         for p in self.ac.parameters():
             p.grad = torch.ones_like(p)
-        self.kl = torch.zeros(1, dtype=torch.float64, device=env.device)
+        self.kl32 = torch.zeros(1, dtype=torch.float32, device=env.device)
         self.ones = torch.ones(1, dtype=torch.float64, device=env.device)
-        self.nbytes = sum(p.numel() for p in self.ac.parameters()) * 4
+        self.nbytes = (sum(p.numel() for p in self.ac.parameters()) + 1) * 4
 
     def step(self):
-        self.tr._allreduce_grads()              # ONE flattened bucket, sum then / world
-        if self.dist is not None:
-            self.dist.all_reduce(self.kl)       # the KL mean (kept on the device: no host sync here)
+        # ONE collective: the flattened bucket (sum, then / world) with the KL estimate in its last
+        # slot, exactly as multi_ppo's policy pass issues it (the mean KL is left on the device here:
+        # the trainer's host read of it is not part of the collective's cost)
+        d = self.dist
+        if d is None:
+            return
+        flat = self.tr._bucket()
+        flat[-1:].copy_(self.kl32)
+        d.all_reduce(flat)
+        flat /= d.get_world_size()
 
     def ranks_seen(self):
         t = self.ones.clone()
@@ -249,8 +256,8 @@ def main():
                     backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none (1 rank)",
                     allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
                     overlapped=side is not None,
-                    bucket_bytes=bucket.nbytes, per_step="gradient bucket all-reduce + KL mean all-reduce "
-                    "(multi_ppo._allreduce_grads / update), once per timed env step")
+                    bucket_bytes=bucket.nbytes, per_step="ONE all-reduce of the gradient bucket with the KL estimate in its last slot "
+                    "(multi_ppo._allreduce_grads), once per timed env step")
 
     if rank == 0:
         total_units = world * E * N * K

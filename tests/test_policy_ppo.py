@@ -206,6 +206,25 @@ def test_pooled_update_warns_about_max_update_num():
         multi_ppo(_FakeEnv(), mlp_ac(21, hidden_sizes=(8, 8)), steps_per_epoch=2, max_update_num=3)
 
 
+def test_kl_stop_is_decided_by_the_mean_over_ranks():
+    """The KL estimate travels in the last slot of the gradient bucket: both ranks see the same mean,
+    stop before the same optimizer step (multi_ppo.py:362) and stay identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q, 1e-4, 200)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (w0, steps0, kl0), (w1, steps1, kl1) = out[0], out[1]
+    assert steps0 == steps1 and 1 <= steps0 < 200, (steps0, steps1)
+    assert kl0 == kl1 and kl0 > 1e-4
+    np.testing.assert_array_equal(w0, w1)
+
+
 def test_mlp_ac_surface():
     ac = mlp_ac(102)
     obs = torch.randn(5, 102)
@@ -221,22 +240,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _ddp_worker(rank, world, port, q):
+def _ddp_worker(rank, world, port, q, target_kl=1e9, iters=3):
     import torch.distributed as dist
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     dist.init_process_group("gloo")
     torch.manual_seed(0)
     ac = mlp_ac(21, hidden_sizes=(16, 16))
-    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, train_pi_iters=3, train_v_iters=2,
-                   target_kl=1e9, use_gpu=False, dist=dist, seed=0)
+    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, train_pi_iters=iters, train_v_iters=2,
+                   target_kl=target_kl, use_gpu=False, dist=dist, seed=0)
     g = torch.Generator().manual_seed(100 + rank)  # every rank has its own shard of samples
     n = 64
     data = dict(obs=torch.randn(n, 21, generator=g), act=torch.randn(n, 3, generator=g) * 0.3,
                 adv=torch.randn(n, generator=g), ret=torch.randn(n, generator=g),
                 logp=torch.randn(n, generator=g) * 0.1 - 2.0)
-    tr.update(data)
-    q.put((rank, torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()))
+    if target_kl < 1e9:  # log-probs of the policy that "collected" the samples: KL starts at 0 and grows
+        with torch.no_grad():
+            data["logp"] = ac.pi(data["obs"], data["act"])[1]
+    st = tr.update(data)
+    out = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()
+    q.put((rank, out) if target_kl >= 1e9 else (rank, (out, st["pi_steps"], st["kl"])))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -63,19 +63,19 @@ def _bucket_worker(rank, world, port, q):
     b = bench.GradBucket(Env(), dist)
     for p in b.ac.parameters():
         p.grad = torch.full_like(p, float(rank + 1))   # rank 0: 1, rank 1: 2 -> mean 1.5
-    b.kl += rank
+    b.kl32 += rank                                     # rank 0: 0, rank 1: 1 -> mean 0.5, in the bucket's last slot
     b.step()
     seen = b.ranks_seen()
     g = torch.cat([p.grad.reshape(-1) for p in b.ac.parameters()])
-    q.put((rank, seen, float(g.min()), float(g.max()), float(b.kl), b.nbytes))
+    q.put((rank, seen, float(g.min()), float(g.max()), float(b.tr._bucket()[-1]), b.nbytes))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_bench_gradient_bucket_collective_two_ranks():
     """bench.py's N > 1 leg on CPU (gloo, world_size 2): the trainer's flattened gradient bucket
-    is averaged over the ranks, the KL scalar summed, and ranks_seen comes from a real
-    all-reduce.  0.74 MB = the MLP(256,256) policy of BASELINE config 3."""
+    is averaged over the ranks in ONE all-reduce, the KL estimate riding in its last slot, and
+    ranks_seen comes from a real all-reduce.  0.74 MB = the MLP(256,256) policy of BASELINE config 3."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -87,7 +87,7 @@ def test_bench_gradient_bucket_collective_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     for rank, seen, gmin, gmax, kl, nbytes in out:
-        assert seen == 2 and gmin == gmax == 1.5 and kl == 1.0
+        assert seen == 2 and gmin == gmax == 1.5 and kl == 0.5
         assert 0.70e6 < nbytes < 0.80e6
 
 
