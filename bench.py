@@ -13,8 +13,8 @@ whole batch, with the actions already resident in HBM.
 
 Envs are independent, so N GPUs = N shards of 4096 envs each (weak scaling) and the
 step itself needs no data-path collective.  The one collective of the north-star
-design - the RCCL all-reduce of the flattened policy-gradient bucket plus the mean of
-the KL estimate, once per optimizer step (rvo3d_amd.policy.multi_ppo._allreduce_grads /
+design - the RCCL all-reduce of the flattened policy-gradient bucket, the KL estimate
+in its last slot, once per optimizer step (rvo3d_amd.policy.multi_ppo._allreduce_grads /
 update) - is put INSIDE every timed step whenever N > 1 (or with
 --grad-allreduce): the trainer's own code path on the gradients of the MLP(256,256)
 policy of BASELINE config 3 (0.74 MB fp32).  That is the worst case - one optimizer
