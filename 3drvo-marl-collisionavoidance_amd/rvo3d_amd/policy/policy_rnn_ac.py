@@ -276,7 +276,7 @@ class mlp_ac(nn.Module):
         if len(acts) != len(lin) or not all(isinstance(m, nn.ReLU) for m in acts[:-1]):
             return net(x)
         dt = torch.bfloat16 if torch.is_autocast_enabled() else x.dtype
-        h = x.to(dt)
+        h = x.to(dt)  # (a no-op when the caller already cast the observation: step_tensors does, once for both nets)
         for m in lin[:-1]:
             h = torch._addmm_activation(_cast_cached(m.bias, dt), h, _cast_cached(m.weight, dt).t(), use_gelu=False)
         h = torch.nn.functional.linear(h, _cast_cached(lin[-1].weight, dt), _cast_cached(lin[-1].bias, dt))
@@ -285,6 +285,8 @@ class mlp_ac(nn.Module):
     def step_tensors(self, obs, std_factor=1):
         with torch.no_grad():
             x = self._obs(obs)
+            if torch.is_autocast_enabled():  # one bf16 copy of the [E*N, W] observation for both nets
+                x = x.to(torch.bfloat16)
             mu = self._fused_forward(self.pi_net, x).float()
             std = torch.clamp(std_factor * torch.exp(self.log_std) + 1e-6, min=1e-4, max=10.0)
             d = Normal(mu, std)
