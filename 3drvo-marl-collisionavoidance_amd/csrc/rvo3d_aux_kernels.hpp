@@ -118,7 +118,6 @@ __global__ void __launch_bounds__(512) rvo_vel_kernel(const Params P, const RvoV
     cnt[k] = arange_len(lo[k], hi);
     if (cnt[k] > 4) cnt[k] = 4;  // host checks acceler <= 1
   }
-  const int C = cnt[0] * cnt[1] * cnt[2];  // candidate c = (ix * cnt1 + iy) * cnt2 + iz
   unsigned long long live = 0ull, inside = 0ull;
   // candidate c = (ix * cnt1 + iy) * cnt2 + iz: nested loops, no division by the runtime counts
   {
