@@ -102,6 +102,9 @@ __device__ __forceinline__ PairOut pair_eval(const Params& P, const Drone& S, co
 __device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, int lbase,
                                           const Drone& S, const PairOut& po, int j, int kept) {
   const size_t T = P.S;  // slot stride of the row scratch
+  // (g made opaque: otherwise the two row-scratch addresses are hoisted out of the exact-stage
+  // loop and carried - spilled, at 128 / 256 drones - across it for this rare path)
+  asm volatile("" : "+v"(g));
   double* const iet = P.row_iet(0) + g;
   uint32_t* const pk = P.row_pk(0) + g;
   // position among kept rows: first slot whose row is more urgent than the new one
