@@ -518,14 +518,16 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         const v2f ci = -(cs * wi2), cj = -(cs * wj2), ki = wi2 * K2, kj = wj2 * K2;
 #define RVO3D_X1_HALF(c, jd, pi, pj)                                                          \
         {                                                                                     \
-          const int touch = TOUCH & (int)(d2.c <= tch.c);                                     \
-          const int ai = vi.c > -mkd, aj = vj.c < jkd.c;                                      \
-          const int filt = (int)(gap.c >= P.x1_gap) & (int)(jprio.c == mprio);                \
-          const int oi = si.c < (si.c < 0.f ? ci.c : ki.c);                                   \
-          const int oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                   \
-          pi = (fr | touch | (ai & ~(filt & oi))) & 1;                                        \
-          pj = (fr | touch | (aj & ~(filt & oj))) & 1;                                        \
-          if (ROWS) keep.add(kbit, fr | ai | aj);                                             \
+          /* lane predicates, combined with & | ! (no short circuit: no branches; the        \
+             compiler keeps them as wave masks and combines them on the scalar unit) */       \
+          const bool touch = TOUCH & (d2.c <= tch.c);                                         \
+          const bool ai = vi.c > -mkd, aj = vj.c < jkd.c;                                     \
+          const bool filt = (gap.c >= P.x1_gap) & (jprio.c == mprio);                         \
+          const bool oi = si.c < (si.c < 0.f ? ci.c : ki.c);                                  \
+          const bool oj = sj.c < (sj.c < 0.f ? cj.c : kj.c);                                  \
+          pi = far | touch | (ai & !(filt & oi));                                             \
+          pj = far | touch | (aj & !(filt & oj));                                             \
+          if (ROWS) keep.add(kbit, (int)(far | ai | aj));                                     \
         }
         bool pi0, pj0, pi1, pj1;
         {

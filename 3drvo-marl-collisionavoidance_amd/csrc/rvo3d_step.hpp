@@ -723,6 +723,13 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       const double v0[3] = {0, 0, 0};
       stage_f32<NW>(P, L, el, d, true, p, v0, az, S.r, S.prio);
     }
+    // an env that reset somebody is observed with action 0 (ir_gym.py:372-383): its drones zero the
+    // fp32 copy of their action now (any_reset is visible since the barrier above; the rows sweep is
+    // behind the next one), so stage X1 needs no per-trip "action or zero" selects
+    if (active && L.any_reset[el] != 0) {
+      const int os = el * N + d;
+      L.w[WAX][os] = 0.f; L.w[WAY][os] = 0.f; L.w[WAZ][os] = 0.f;
+    }
   }
   // everything about this drone except its VO rows is final now.  The stores wait until
   // after the last sweep (vector memory returns in order: a load behind a store waits for
@@ -744,7 +751,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     // ir_gym.env_observation with action 0 (the env reset a drone, ir_gym.py:372-383)
     const bool env_reset = active && (L.any_reset[el] != 0);
     bool c2 = false;
-    const double* aa = env_reset ? zero3 : az;
+    const double aa[3] = {env_reset ? 0.0 : az[0], env_reset ? 0.0 : az[1], env_reset ? 0.0 : az[2]};
     // stage G: the collision sweep delivered the words of the post-move state; only pairs
     // with a reset drone changed since (larger envs: recompute when the env reset anyone)
     bool have_gw2 = !env_reset;
@@ -765,7 +772,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
     RVO3D_STAMP(27);
     kept = sweep_env<NW, true, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
-                                      env_reset, flag, tmin, c2, gw, have_gw2);
+                                      false, flag, tmin, c2, gw, have_gw2);
   }
   RVO3D_STAMP(7);
   // kept rows first (their loads from the row scratch would otherwise queue behind the fill's
