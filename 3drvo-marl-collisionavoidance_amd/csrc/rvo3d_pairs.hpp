@@ -431,8 +431,11 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f mex2 = {mex, mex}, mey2 = {mey, mey}, mez2 = {mez, mez}, mer2 = {mer, mer};
     const v2f mvx2 = {mvx, mvx}, mvy2 = {mvy, mvy}, mvz2 = {mvz, mvz};
-    const v2f tax = {2.f * max_, 2.f * max_}, tay = {2.f * may, 2.f * may},
-              taz = {2.f * maz, 2.f * maz};
+    // (the cone filter below works with 2 w = 4 a - (v_i + v_j): every term of its comparisons is
+    // homogeneous of degree 2 in w and a factor 2 is exact in binary, so the decisions are those of
+    // w = 2 a - (v_i + v_j) / 2 bit for bit, without the three halvings per trip)
+    const v2f tax = {4.f * max_, 4.f * max_}, tay = {4.f * may, 4.f * may},
+              taz = {4.f * maz, 4.f * maz};
     const int fr = far ? 1 : 0;
 #ifndef RVO3D_X1_CW
 #define RVO3D_X1_CW 4
@@ -495,17 +498,16 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         const v2f Kr = (v2f){0.999998f, 0.999998f} * sq_ - (v2f){2.0e-3f, 2.0e-3f} * rs;
         const v2f K = {__builtin_fmaxf(Kr.x, 0.f), __builtin_fmaxf(Kr.y, 0.f)};
         const v2f K2 = K * K * (v2f){P.x1_k2, P.x1_k2};
-        const v2f hf = {0.5f, 0.5f};
-        const v2f hx = hf * (mvx2 + jvx), hy = hf * (mvy2 + jvy), hz = hf * (mvz2 + jvz);
-        // w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
+        const v2f hx = mvx2 + jvx, hy = mvy2 + jvy, hz = mvz2 + jvz;
+        // 2 w_i, w_i = 2 a_i - (v_i + v_j) / 2  (get_PAA with equal priorities)
         const v2f wix = tax - hx, wiy = tay - hy, wiz = taz - hz;
         const v2f dpi = __builtin_elementwise_fma(
             dz, wiz, __builtin_elementwise_fma(dy, wiy, dx * wix));
         const v2f wi2 = __builtin_elementwise_fma(
             wiz, wiz, __builtin_elementwise_fma(wiy, wiy, wix * wix));
-        // seen from j: rel -> -rel, w_j = 2 a_j - (v_i + v_j) / 2
-        const v2f two2 = {2.f, 2.f};
-        const v2f wjx = two2 * ajx - hx, wjy = two2 * ajy - hy, wjz = two2 * ajz - hz;
+        // seen from j: rel -> -rel, 2 w_j = 4 a_j - (v_i + v_j)
+        const v2f four2 = {4.f, 4.f};
+        const v2f wjx = four2 * ajx - hx, wjy = four2 * ajy - hy, wjz = four2 * ajz - hz;
         const v2f dpj = -__builtin_elementwise_fma(
             dz, wjz, __builtin_elementwise_fma(dy, wjy, dx * wjx));
         const v2f wj2 = __builtin_elementwise_fma(

@@ -117,3 +117,22 @@ def test_fmod_shortcut_for_one_period_either_side():
     m[nz & (m < 0)] += b
     m[~nz] = 0.0
     assert np.array_equal(m, np.mod(a, b))
+
+
+def test_doubling_w_is_exact_in_float32():
+    """Stage X1 works with 2 w = 4 a - (v_i + v_j) instead of w = 2 a - (v_i + v_j) / 2
+    (rvo3d_pairs.hpp): the two are exactly a factor 2 apart in float32, operation by operation, so
+    every comparison of the cone filter - homogeneous of degree 2 in w - decides the same."""
+    rng = np.random.default_rng(6)
+    n = 500000
+    f = np.float32
+    a = np.round(rng.uniform(-3, 3, n), 2).astype(f)
+    vi = rng.normal(0, 1.2, n).astype(f)
+    vj = rng.normal(0, 1.2, n).astype(f)
+    vi[rng.random(n) < 0.1] = 0
+    w = f(2) * a - f(0.5) * (vi + vj)
+    w2 = f(4) * a - (vi + vj)
+    assert w.dtype == np.float32 and w2.dtype == np.float32
+    assert np.array_equal(f(2) * w, w2)
+    d = rng.uniform(-10, 10, n).astype(f)
+    assert np.array_equal(f(2) * (d * w), d * w2) and np.array_equal(f(4) * (w * w), w2 * w2)
