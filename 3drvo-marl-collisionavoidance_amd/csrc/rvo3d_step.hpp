@@ -568,14 +568,33 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   double mov_nc = 0;  // mov_reward (k form) if the step turns out collision-free
   bool f_dest = false;
   RVO3D_STAMP(3);
+  // (the whole batch is issued here, ahead of the barrier below - a fence the compiler does not move
+  // loads across: what the integration needs arrives while the RVO reward is being computed)
+  // (up to 128 drones per env; at 256 the eighteen registers this keeps busy over the barrier cost more
+  // than the latency they hide)
+  constexpr bool kLoadAhead = NW <= 2;
+  double prev[3] = {0, 0, 0}, yaw = 0, pitch = 0, real_len = 0, route_len = 0;
+  int npts = 2;
+  bool f_arrive_in = false, f_dest_in = false;
+#define RVO3D_LOAD_INTEGRATION_STATE()                                               \
+  {                                                                                  \
+    wpi = P.wp_idx()[g];                                                             \
+    RVO3D_LOAD_PREV(P, g, prev);                                                     \
+    yaw = P.yaw()[g]; pitch = P.pitch()[g]; real_len = P.real_len()[g];              \
+    route_len = P.route_len()[g];                                                    \
+    npts = P.n_points()[g];                                                          \
+    f_arrive_in = P.arrive()[g] != 0; f_dest_in = P.dest()[g] != 0;                  \
+  }
   if (active) {
     max_dev = P.max_dev()[g];
     RVO3D_LOAD_CUR(P, g, cur);
+    uint32_t dvk_a = 0, dvk_b = 0;
+    if (P.dv_cached) { dvk_a = P.dvk_a()[g]; dvk_b = P.dvk_b()[g]; }
+    if (kLoadAhead) RVO3D_LOAD_INTEGRATION_STATE()
     bool have = false;
-    if (P.dv_cached) have = dv_decode(P.dvk_a()[g], P.dvk_b()[g], dv);
+    if (P.dv_cached) have = dv_decode(dvk_a, dvk_b, dv);
     if (!have) {
-      double prev[3];
-      RVO3D_LOAD_PREV(P, g, prev);
+      if (!kLoadAhead) RVO3D_LOAD_PREV(P, g, prev);
       const double p[3] = {S.x, S.y, S.z};
       des_vel(P, p, cur, dv);
       dev = deviation(prev, cur, p);
@@ -586,18 +605,13 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   RVO3D_STAMP(18);
   __syncthreads();  // everyone is done with the pre-move LDS image
   if (active) {
-    double prev[3];
-    wpi = P.wp_idx()[g];
-    RVO3D_LOAD_PREV(P, g, prev);
-    double yaw = P.yaw()[g], pitch = P.pitch()[g], real_len = P.real_len()[g];
+    if (!kLoadAhead) RVO3D_LOAD_INTEGRATION_STATE()
+#undef RVO3D_LOAD_INTEGRATION_STATE
     // extra_len is only ever WRITTEN by the step (drone.py:188, ir_gym.py:176): not loaded, and
     // stored only by the drones that set it; wp_idx / arrive / dest likewise only when they change
     bool ex_set = false;
     double extra_len = 0.0;
-    const double route_len = P.route_len()[g];
-    const int npts = P.n_points()[g];
     const int wpi_in = wpi;
-    const bool f_arrive_in = P.arrive()[g] != 0, f_dest_in = P.dest()[g] != 0;
     bool f_arrive = f_arrive_in;
     f_dest = f_dest_in;
 
@@ -702,14 +716,27 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     if (active && P.reset_mask) P.reset_mask[g] = do_reset ? 1 : 0;
     if (do_reset) L.any_reset[el] = 1;
     __syncthreads();  // sweep reads done; any_reset visible
-    if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
-      double p[3];
+    // the reset drones' start state is requested first; then - the workgroup's early zero blocks
+    // (two-phase row writer: every 64-B block without proprio bytes) are stored, which takes a
+    // few thousand cycles of store issue and needs no data at all: the loads land meanwhile
+    double p[3] = {0, 0, 0}, rcur[3] = {0, 0, 0}, rdev = 0.0;
+    uint32_t rdv_a = 0, rdv_b = 0;
+    if (do_reset) {  // (dronestate of the start state: static, tabulated by rvo3d_load_world, dv0_kernel)
       load_wp(P, g, 0, p);
+      rdev = P.dev0()[g];
+      load_wp(P, g, 1, rcur);
+      rdv_a = P.dv0_a()[g]; rdv_b = P.dv0_b()[g];
+    }
+    RVO3D_STAMP(26);
+    // (one-wave workgroups: 64 x 4096 -2 %; with several waves per workgroup the blocks go out right
+    // before the rows sweep instead, which measured better there)
+    if (NW == 1 && two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
+    RVO3D_STAMP(27);
+    if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
       S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
-      // dronestate of the start state: static, tabulated by rvo3d_load_world (dv0_kernel)
-      dev = P.dev0()[g];
-      load_wp(P, g, 1, cur);
-      if (!dv_decode(P.dv0_a()[g], P.dv0_b()[g], dv)) {
+      dev = rdev;
+      cur[0] = rcur[0]; cur[1] = rcur[1]; cur[2] = rcur[2];
+      if (!dv_decode(rdv_a, rdv_b, dv)) {
         des_vel(P, p, cur, dv);
         dev = deviation(p, cur, p);  // previous_des = waypoints[0] = the start position
       }
@@ -767,10 +794,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       have_gw2 = true;
     }
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
-    RVO3D_STAMP(26);
-    // two-phase row writer: the zeros of every block without proprio bytes leave now
-    if (two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
-    RVO3D_STAMP(27);
+    if (NW > 1 && two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
     kept = sweep_env<NW, true, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       false, flag, tmin, c2, gw, have_gw2);
   }

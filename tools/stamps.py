@@ -44,8 +44,8 @@ if s[:, 24:26].any():
     print(f"  X1 candidates per lane in the rows sweep: mean {s[:, 24].mean() / T_:.3f}; busiest lane of a workgroup: mean {s[:, 25].mean():.2f} "
           f"p95 {np.percentile(s[:, 25], 95):.0f} (trips = half of it)")
 if s[:, 26:28].any():
-    print(f"  before the rows sweep: re-gate after resets {(s[:, 26] - s[:, 6]).mean():8.0f}  early zero blocks {(s[:, 27] - s[:, 26]).mean():8.0f}  "
-          f"sweep entry (masks, own record) {(s[:, 10] - s[:, 27]).mean():8.0f}")
+    print(f"  reset phase: decision + barrier + reset loads issued {(s[:, 26] - s[:, 5]).mean():8.0f}  early zero blocks {(s[:, 27] - s[:, 26]).mean():8.0f}  "
+          f"reset state, stores, restage {(s[:, 6] - s[:, 27]).mean():8.0f}  re-gate + sweep entry {(s[:, 10] - s[:, 6]).mean():8.0f}")
 life = s[:, 9] - s[:, 0]
 print("wave life mean", life.mean(), "start spread", s[:, 0].max() - s[:, 0].min(), "end-start", s[:, 9].max() - s[:, 0].min())
 
