@@ -458,11 +458,17 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
 
   // ---- phase 0: the drone's own record and its action; everything else about the pre-move
   //      state (waypoints, des_vel, deviation) is fetched after sweep A, which needs none of it
+  uint32_t gw[NW];  // candidate words (stage G): on file from the previous step if it ended in this state
+  const bool have_gw = MODE != kObserve && P.g_cached != 0;
   if (active) {
     S.x = P.px()[g]; S.y = P.py()[g]; S.z = P.pz()[g];
     S.vx = P.vx()[g]; S.vy = P.vy()[g]; S.vz = P.vz()[g];
     if (P.uniform_rp) { S.r = P.r0; S.prio = P.prio0; }
     else { S.r = P.radius()[g]; S.prio = P.prio()[g]; }
+    if (have_gw) {  // requested with the record: sweep A's stage X1 starts from them (no load behind the staging barrier)
+#pragma unroll
+      for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
+    }
     if (MODE != kObserve) {
       if (P.action_mode == 1) {
         // The trainer's glue (multi_ppo.py:196-205), in numpy's own types:
@@ -523,7 +529,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       dev = deviation(prev, cur, p);
       if (dev > max_dev) max_dev = dev;
     }
-    uint32_t gw[NW];
     const int kept = sweep_env<NW, true, true, TRAIN, GSH>(P, L, tid, el, d, g, active, S, zero3, true, flag,
                                                tmin, collision, gw, false);
     if (active) {
@@ -549,12 +554,6 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
 
   RVO3D_STAMP(2);
   // ---- sweep A: ir_gym.rvo_reward_list_cal on the pre-move state (ir_gym.py:50-62)
-  uint32_t gw[NW];
-  const bool have_gw = P.g_cached != 0;  // the previous step ended in this very state
-  if (have_gw && active) {
-#pragma unroll
-    for (int w = 0; w < NW; ++w) gw[w] = P.gcache(w)[g];
-  }
   sweep_env<NW, false, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(1), S, az, false, flag,
                               tmin, collision, gw, have_gw);
   // ---- everything else about this drone arrives in ONE batch of loads now (none of the
