@@ -218,8 +218,13 @@ __device__ __forceinline__ void early_zero_blocks(const Params& P, const Lds& L,
   uint32_t m = P.cold().zmask[tid >> 2];
   char* p = base + (size_t)blk * 64u + 16u * ((uint32_t)ln & 3u);
   const size_t step = (size_t)1024 * (size_t)nwv;
-  for (int i = 0; i < iters; ++i, p += step, m >>= 1)
-    if (m & 1u) __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(p));
+  // four trips per loop pass (bits beyond the last trip are 0: nothing is stored for them)
+  for (int i = 0; i < iters; i += 4, p += 4 * step, m >>= 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if ((m >> u) & 1u)
+        __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(p + u * step));
+  }
 }
 
 // part 2: per row the 128-B window that starts at the 64-B block holding the row's first byte: the
