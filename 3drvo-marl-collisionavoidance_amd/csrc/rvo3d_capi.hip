@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -26,6 +28,23 @@ int fail(int code, const std::string& msg) {
     if (_e != hipSuccess)                                                        \
       return fail(RVO3D_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
+
+// "Nothing throws" (include/rvo3d.h): every entry point that returns a status runs between these two.
+// A host allocation that fails (std::vector staging in rvo3d_load_world, the error string itself) or
+// any other C++ exception becomes RVO3D_ERR_INVALID instead of crossing the extern "C" boundary.
+int api_caught(const char* what) noexcept {
+  try {
+    g_err = std::string("C++ exception: ") + what;
+  } catch (...) {
+    try { g_err.clear(); } catch (...) { }
+  }
+  return RVO3D_ERR_INVALID;
+}
+#define RVO3D_API_BEGIN try {
+#define RVO3D_API_END                                              \
+  }                                                                \
+  catch (const std::exception& e) { return api_caught(e.what()); } \
+  catch (...) { return api_caught("unknown"); }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 // x ** 2 as the reference computes it: glibc pow (the volatile exponent keeps
@@ -118,27 +137,50 @@ int check(rvo3d_env* h, bool need_world, DeviceGuard& g) {
   return g.enter(h->cfg.device);
 }
 
+// The compile-time-N instantiation (NFIX) a handle's shape selects, 0 = the generic kernel of its NW.
+// One place decides it: launch_nw() launches it and rvo3d_kernel_name() reports it.
+int pick_nfix(const Params& P) {
+  if (P.nw == 1) {
+    if ((P.N == 64 && P.epb == 1) || (P.N == 32 && P.epb == 2) || (P.N == 16 && P.epb == 4)) return P.N;
+    return 0;
+  }
+  if (!P.env_train) return 0;  // (the evaluator's multi-wave envs run the generic kernels)
+  if (P.nw == 2 && P.N == 128) return 128;
+  if (P.nw == 4 && P.N == 256) return 256;
+  return 0;
+}
+
+template <int MODE, int NW, int NFIX, bool TRAIN>
+void launch_inst(rvo3d_env* h, const Params& P, hipStream_t s) {
+  hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NFIX, TRAIN>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+}
+
 template <int MODE, int NW>
 int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
-  if (!P.env_train) {  // the evaluator's env (train/policy_test.py:46): its own instantiations
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, 0, false>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
-  } else if (NW == 1 && P.N == 64 && P.epb == 1) {  // compile-time N (see env_kernel)
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 64 : 0>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
-  } else if (NW == 1 && P.N == 32 && P.epb == 2) {
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 32 : 0>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
-  } else if (NW == 1 && P.N == 16 && P.epb == 4) {
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 1 ? 16 : 0>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
-  } else if (NW == 2 && P.N == 128) {
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 2 ? 128 : 0>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
-  } else if (NW == 4 && P.N == 256) {
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NW == 4 ? 256 : 0>), dim3(h->blocks), dim3(h->threads),
-                       h->lds, s, P);
+  const int nfix = pick_nfix(P);
+  if (NW == 1) {
+    // one-wave workgroups: both env_train modes have their compile-time-N instantiations (the
+    // evaluator of train/policy_test.py:46 runs env_train = False at 16 / 32 / 64 drones too)
+    constexpr int W1 = NW == 1 ? 1 : NW;  // (keeps the other NW from instantiating these)
+    if (P.env_train) {
+      if (nfix == 64) launch_inst<MODE, W1, NW == 1 ? 64 : 0, true>(h, P, s);
+      else if (nfix == 32) launch_inst<MODE, W1, NW == 1 ? 32 : 0, true>(h, P, s);
+      else if (nfix == 16) launch_inst<MODE, W1, NW == 1 ? 16 : 0, true>(h, P, s);
+      else launch_inst<MODE, NW, 0, true>(h, P, s);
+    } else {
+      if (nfix == 64) launch_inst<MODE, W1, NW == 1 ? 64 : 0, false>(h, P, s);
+      else if (nfix == 32) launch_inst<MODE, W1, NW == 1 ? 32 : 0, false>(h, P, s);
+      else if (nfix == 16) launch_inst<MODE, W1, NW == 1 ? 16 : 0, false>(h, P, s);
+      else launch_inst<MODE, NW, 0, false>(h, P, s);
+    }
+  } else if (!P.env_train) {
+    launch_inst<MODE, NW, 0, false>(h, P, s);
+  } else if (NW == 2 && nfix == 128) {
+    launch_inst<MODE, NW, NW == 2 ? 128 : 0, true>(h, P, s);
+  } else if (NW == 4 && nfix == 256) {
+    launch_inst<MODE, NW, NW == 4 ? 256 : 0, true>(h, P, s);
   } else {
-    hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+    launch_inst<MODE, NW, 0, true>(h, P, s);
   }
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
@@ -177,6 +219,7 @@ int rvo3d_version(void) { return RVO3D_VERSION; }
 const char* rvo3d_last_error(void) { return g_err.c_str(); }
 
 int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
+  RVO3D_API_BEGIN
   if (!cfg || !out) return fail(RVO3D_ERR_INVALID, "null argument");
   *out = nullptr;
   if (cfg->num_envs < 1 || cfg->num_drones < 1 || cfg->num_drones > rvo3d::kMaxThreads)
@@ -191,6 +234,15 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
 
   rvo3d_env* h = new (std::nothrow) rvo3d_env();
   if (!h) return fail(RVO3D_ERR_INVALID, "out of host memory");
+  // owns h until the very end: every early return - and an exception - frees the handle and its arena
+  struct Owner {
+    rvo3d_env* p;
+    ~Owner() {
+      if (!p) return;
+      if (p->arena) (void)hipFree(p->arena);
+      delete p;
+    }
+  } owner{h};
   h->cfg = *cfg;
   Params& P = h->P;
   rvo3d::Cold& C = h->cold;
@@ -265,7 +317,6 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   if (const char* pad = std::getenv("RVO3D_LDS_PAD")) lds += (size_t)std::atoi(pad);  // diagnostics build only: cap occupancy
 #endif
   if (lds > 160 * 1024) {
-    delete h;
     return fail(RVO3D_ERR_INVALID, "neighbors_num * num_drones needs more than 160 KiB of LDS");
   }
   P.epb = epb;
@@ -278,7 +329,6 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
     const uint64_t qmax = (uint64_t)threads * C.zf_div;
     for (uint64_t q = 0; q < qmax && ok; ++q) ok = ((q * m) >> 32) == q / C.zf_div;
     if (!ok) {
-      delete h;
       return fail(RVO3D_ERR_INVALID, "neighbors_num too large for the zero-fill index trick");
     }
     C.zf_magic = m;
@@ -286,6 +336,8 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   C.zf_q = (P.W & 1) == 0 ? (uint32_t)(P.W / 2) : 0u;  // row bytes / 8: the 16-B row writer applies
   // early_zero_blocks: which of its trips a thread quad stores in depends on W and the quad only
   C.zf_iters = 0;
+  static_assert(rvo3d::kMaxThreads / 4 <= sizeof(C.zmask) / sizeof(C.zmask[0]),
+                "Cold::zmask has one word per thread quad of the largest workgroup");
   std::memset(C.zmask, 0, sizeof C.zmask);
   {
     const uint32_t rb = 4u * (uint32_t)P.W;
@@ -314,21 +366,19 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
                   : P.nw == 2 ? allow_lds_all<2>((int)lds)
                   : P.nw == 4 ? allow_lds_all<4>((int)lds) : allow_lds_all<8>((int)lds);
     if (!ok) {
-      delete h;
       return fail(RVO3D_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
   }
   int rc = carve(h);
-  if (rc != RVO3D_OK) {
-    if (h->arena) (void)hipFree(h->arena);
-    delete h;
-    return rc;
-  }
+  if (rc != RVO3D_OK) return rc;
+  owner.p = nullptr;
   *out = h;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_destroy(rvo3d_env* h) {
+  RVO3D_API_BEGIN
   if (!h) return RVO3D_OK;
   DeviceGuard dg;
   (void)dg.enter(h->cfg.device);
@@ -336,11 +386,13 @@ int rvo3d_destroy(rvo3d_env* h) {
   if (h->arena) (void)hipFree(h->arena);
   delete h;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_points,
                      const double* buildings, const double* radius, const double* priority,
                      void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, false, dg);
   if (rc) return rc;
@@ -441,9 +493,11 @@ int rvo3d_load_world(rvo3d_env* h, const double* waypoints, const int32_t* n_poi
   h->dv_valid = true;  // reset_kernel filed the des_vel of every start state
   h->g_valid = false;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -453,9 +507,11 @@ int rvo3d_reset(rvo3d_env* h, const uint8_t* env_mask, void* stream) {
                      static_cast<hipStream_t>(stream), h->P, env_mask, (const uint8_t*)nullptr);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -466,9 +522,11 @@ int rvo3d_reset_drones(rvo3d_env* h, const uint8_t* drone_mask, void* stream) {
                      static_cast<hipStream_t>(stream), h->P, (const uint8_t*)nullptr, drone_mask);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -479,11 +537,13 @@ int rvo3d_observe(rvo3d_env* h, float* obs, int32_t* vo_count, void* stream) {
   rc = launch<rvo3d::kObserve>(h, P, static_cast<hipStream_t>(stream));
   if (rc == RVO3D_OK) h->dv_valid = h->g_valid = true;  // observe files des_vel and the stage-G words
   return rc;
+  RVO3D_API_END
 }
 
 static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
                        int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                        uint8_t* finish, uint8_t* reset_mask, bool autoreset, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -502,18 +562,22 @@ static int step_common(rvo3d_env* h, const void* actions, int32_t action_dtype, 
   rc = autoreset ? launch<rvo3d::kStepAutoReset>(h, P, s) : launch<rvo3d::kStep>(h, P, s);
   if (rc == RVO3D_OK) h->dv_valid = h->g_valid = true;  // every step files both for the state it ends in
   return rc;
+  RVO3D_API_END
 }
 
 int rvo3d_step(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
                int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info, uint8_t* finish,
                void* stream) {
+  RVO3D_API_BEGIN
   return step_common(h, actions, action_dtype, obs, vo_count, reward, done, info, finish, nullptr,
                      false, stream);
+  RVO3D_API_END
 }
 
 static int step_policy_common(rvo3d_env* h, const float* a_inc, float acceler, float* obs,
                               int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                               uint8_t* finish, uint8_t* reset_mask, bool autoreset, void* stream) {
+  RVO3D_API_BEGIN
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   h->P.action_mode = 1;
   h->P.acceler = acceler;
@@ -521,29 +585,37 @@ static int step_policy_common(rvo3d_env* h, const float* a_inc, float acceler, f
                              reset_mask, autoreset, stream);
   h->P.action_mode = 0;
   return rc;
+  RVO3D_API_END
 }
 
 int rvo3d_step_policy(rvo3d_env* h, const float* a_inc, float acceler, float* obs,
                       int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                       uint8_t* finish, uint8_t* reset_mask, int32_t autoreset, void* stream) {
+  RVO3D_API_BEGIN
   return step_policy_common(h, a_inc, acceler, obs, vo_count, reward, done, info, finish,
                             reset_mask, autoreset != 0, stream);
+  RVO3D_API_END
 }
 
 int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype, float* obs,
                          int32_t* vo_count, float* reward, uint8_t* done, uint8_t* info,
                          uint8_t* finish, uint8_t* reset_mask, void* stream) {
+  RVO3D_API_BEGIN
   return step_common(h, actions, action_dtype, obs, vo_count, reward, done, info, finish,
                      reset_mask, true, stream);
+  RVO3D_API_END
 }
 
 int rvo3d_set_reward_f64(rvo3d_env* h, double* reward64) {
+  RVO3D_API_BEGIN
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   h->P.reward64 = reward64;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -553,9 +625,11 @@ int rvo3d_des_vel(rvo3d_env* h, double* des_vel, void* stream) {
                      static_cast<hipStream_t>(stream), h->P, des_vel);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_rvo_vel(rvo3d_env* h, const double* vmax, double acceler, double* out_vel, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -570,20 +644,24 @@ int rvo3d_rvo_vel(rvo3d_env* h, const double* vmax, double acceler, double* out_
                      (size_t)T * 8 * sizeof(double), static_cast<hipStream_t>(stream), h->P, A, out_vel);
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_state_ptrs(rvo3d_env* h, rvo3d_state_view* out) {
+  RVO3D_API_BEGIN
   if (!h || !out) return fail(RVO3D_ERR_INVALID, "null argument");
   const Params& P = h->P;
   out->px = P.px(); out->py = P.py(); out->pz = P.pz(); out->vx = P.vx(); out->vy = P.vy(); out->vz = P.vz();
   out->yaw = P.yaw(); out->pitch = P.pitch(); out->real_len = P.real_len(); out->max_dev = P.max_dev();
   out->extra_len = P.extra_len(); out->wp_idx = P.wp_idx(); out->arrive = P.arrive(); out->dest = P.dest();
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_get_state(rvo3d_env* h, double* pos, double* vel, double* yaw, double* pitch,
                     double* real_len, double* max_dev, double* extra_len, int32_t* wp_idx,
                     uint8_t* arrive, uint8_t* dest, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -604,12 +682,14 @@ int rvo3d_get_state(rvo3d_env* h, double* pos, double* vel, double* yaw, double*
   if (arrive) HIP_TRY(hipMemcpyAsync(arrive, P.arrive(), (size_t)EN, k, s));
   if (dest) HIP_TRY(hipMemcpyAsync(dest, P.dest(), (size_t)EN, k, s));
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const double* yaw,
                     const double* pitch, const double* real_len, const double* max_dev,
                     const double* extra_len, const int32_t* wp_idx, const uint8_t* arrive,
                     const uint8_t* dest, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, true, dg);
   if (rc) return rc;
@@ -634,9 +714,11 @@ int rvo3d_set_state(rvo3d_env* h, const double* pos, const double* vel, const do
   if (arrive) HIP_TRY(hipMemcpyAsync(P.arrive(), arrive, (size_t)EN, k, s));
   if (dest) HIP_TRY(hipMemcpyAsync(P.dest(), dest, (size_t)EN, k, s));
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
+  RVO3D_API_BEGIN
   DeviceGuard dg;
   int rc = check(h, false, dg);
   if (rc) return rc;
@@ -646,26 +728,41 @@ int rvo3d_error_flags(rvo3d_env* h, uint32_t* flags, void* stream) {
   HIP_TRY(hipMemsetAsync(h->P.err, 0, 4, s));
   HIP_TRY(hipStreamSynchronize(s));
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 #ifdef RVO3D_DIAG
 // diagnostics build only (librvo3d_hip_diag.so, tools/): attach a device buffer
 // [blocks][16] of s_memtime stamps, or NULL to detach
 int rvo3d_debug_stamps(rvo3d_env* h, unsigned long long* stamps) {
+  RVO3D_API_BEGIN
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   h->P.dbg = stamps;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 #endif
 
+int rvo3d_kernel_name(rvo3d_env* h, int32_t mode, char* buf, int32_t cap) {
+  RVO3D_API_BEGIN
+  if (!h || !buf || cap < 1) return fail(RVO3D_ERR_INVALID, "null handle / buffer");
+  if (mode < 0 || mode > 2) return fail(RVO3D_ERR_INVALID, "mode: 0 observe, 1 step, 2 step + auto-reset");
+  std::snprintf(buf, (size_t)cap, "rvo3d::env_kernel<%d, %d, %d, %s>", (int)mode, h->P.nw, pick_nfix(h->P),
+                h->P.env_train ? "true" : "false");
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
 int rvo3d_launch_info(rvo3d_env* h, int32_t* threads, int32_t* envs_per_block, int32_t* blocks,
                       int32_t* lds_bytes) {
+  RVO3D_API_BEGIN
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
   if (threads) *threads = h->threads;
   if (envs_per_block) *envs_per_block = h->P.epb;
   if (blocks) *blocks = h->blocks;
   if (lds_bytes) *lds_bytes = h->lds;
   return RVO3D_OK;
+  RVO3D_API_END
 }
 
 }  // extern "C"

@@ -77,7 +77,7 @@ SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
            "rvo3d_step_policy", "rvo3d_set_reward_f64",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
-           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_version", "rvo3d_last_error")
+           "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_kernel_name", "rvo3d_version", "rvo3d_last_error")
 
 _lib = None
 
@@ -110,6 +110,7 @@ def lib():
     L.rvo3d_set_state.argtypes = [vp] * 12
     L.rvo3d_error_flags.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.rvo3d_launch_info.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.rvo3d_kernel_name.argtypes = [vp, i32, C.c_char_p, i32]
     if hasattr(L, "rvo3d_debug_stamps"):  # the diagnostics build (tools/diaglib.py) only
         L.rvo3d_debug_stamps.argtypes = [vp, vp]
         L.rvo3d_debug_stamps.restype = i32

@@ -253,6 +253,13 @@ class BatchedDroneEnv:
         if f & 1:
             raise ValueError("observation contains NaN/Inf")
 
+    def kernel_name(self, mode="step_autoreset") -> str:
+        """The env_kernel instantiation the library launches for `mode` (rvo3d_kernel_name)."""
+        m = {"observe": 0, "step": 1, "step_autoreset": 2}[mode]
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().rvo3d_kernel_name(self._h, m, buf, 128), "rvo3d_kernel_name")
+        return buf.value.decode()
+
     def launch_info(self):
         v = [C.c_int32(0) for _ in range(4)]
         _lib.check(_lib.lib().rvo3d_launch_info(self._h, *[C.byref(x) for x in v]), "launch_info")

@@ -155,9 +155,15 @@ class multi_ppo:
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
                  dist=None, sanitize_rewards=True, amp=False, reference_order=False, **kwargs):
-        torch.manual_seed(seed)
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
+        # The agent order of the reference-order update comes from a generator of its own, seeded like
+        # the reference's global one (multi_ppo.py:104: np.random.seed(seed); a RandomState(seed) draws
+        # the very same sequence): every rank MUST visit the agents in the same order, whatever else in
+        # the process uses np.random.  The action noise, on the other hand, has to differ between the
+        # shards: rank r samples from torch's generator seeded seed + r (rank 0 = the reference's seed).
+        self._order_rng = np.random.RandomState(seed)
+        torch.manual_seed(seed + (dist.get_rank() if (dist is not None and dist.is_initialized()) else 0))
         self.E, self.N = env.E, env.N
         self.robot_num = env.N  # env.ir_gym.drone_num (multi_ppo.py:110)
         self.device = env.device
@@ -197,10 +203,11 @@ class multi_ppo:
         self.log = []
 
     # ---- rollout ------------------------------------------------------------------------
-    def collect(self):
+    def collect(self, final_reset=True):
         """One epoch of steps_per_epoch env steps (multi_ppo.py:183-281), on the device.  The
         env writes each observation straight into the next buffer slot; the policy GEMMs run
-        under ONE autocast region (weight casts are cached across the steps)."""
+        under ONE autocast region (weight casts are cached across the steps).
+        final_reset=False (rollout_profile only) leaves out the epoch-end full reset."""
         env, buf = self.env, self.buf
         cur_obs, cur_cnt = getattr(self, "_cur", (env.obs, env.vo_count))
         buf.obs[0].copy_(cur_obs); buf.cnt[0].copy_(cur_cnt)
@@ -229,7 +236,7 @@ class multi_ppo:
                 self.ep_ret += rew_fin
                 self.ep_len += 1
                 since_full_reset += 1
-                epoch_ended = t == self.steps_per_epoch - 1
+                epoch_ended = final_reset and t == self.steps_per_epoch - 1
                 reset_by_step = (done | fin) != 0        # what the fused step already reset
                 if epoch_ended:                          # full reset (multi_ppo.py:244-264)
                     ended = torch.ones_like(reset_by_step)
@@ -254,6 +261,37 @@ class multi_ppo:
                 self.ep_len.masked_fill_(ended, 0)
         self._cur = (buf.obs[self.steps_per_epoch], buf.cnt[self.steps_per_epoch])
         return float(ret_sum / ret_n.clamp(min=1))
+
+    def rollout_profile(self, steps=4):
+        """What one rollout step costs on the device, for bench.py's `rollout` block: GPU kernel launches
+        per step (torch.profiler over `steps` steps of collect()) and the mean time of the env kernel in
+        them.  Returns {"launches_per_step", "env_kernel_us", "gpu_busy_ms_per_step"}; values are None when
+        the profiler is unavailable (e.g. the process already runs under rocprofv3)."""
+        out = dict(launches_per_step=None, env_kernel_us=None, gpu_busy_ms_per_step=None)
+        if os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            return out
+        T = self.steps_per_epoch
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            self.steps_per_epoch = steps
+            self.buf.ptr = 0
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                self.collect(final_reset=False)
+                torch.cuda.synchronize()
+            ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+            kern = [e for e in ev if "memcpy" not in e.name.lower() and "memset" not in e.name.lower()]
+            envk = [e for e in kern if "env_kernel" in e.name]
+            out["launches_per_step"] = round(len(ev) / steps, 1)
+            out["gpu_busy_ms_per_step"] = round(sum(e.device_time for e in ev) / steps * 1e-3, 4)
+            if envk:
+                out["env_kernel_us"] = round(sum(e.device_time for e in envk) / len(envk), 2)
+        except Exception as ex:  # profiling is a courtesy: never fail the measurement for it
+            out["profile_error"] = f"{type(ex).__name__}: {ex}"
+        finally:
+            self.steps_per_epoch = T
+            self.buf.ptr = 0
+            self.buf.cut.zero_()
+        return out
 
     def training_loop(self):
         self.env.reset()
@@ -393,11 +431,11 @@ class multi_ppo:
 
     def _update_reference_order(self, data_list):
         """The reference's update, statement by statement (multi_ppo.py:341-376): shuffled
-        agent order from numpy's global generator (seeded in the constructor, as the
-        reference's is: every rank draws the same order), max_update_num, per-agent policy
+        agent order from a generator seeded in the constructor exactly as the reference seeds
+        numpy's global one (the same on every rank by construction), max_update_num, per-agent policy
         loop with the KL stop before the step, then the per-agent value loop."""
         randn = np.arange(len(data_list))
-        np.random.shuffle(randn)
+        self._order_rng.shuffle(randn)
         update_num, kl, loss_v = 0, 0.0, torch.zeros(())
         pi_steps = []
         for r in randn:

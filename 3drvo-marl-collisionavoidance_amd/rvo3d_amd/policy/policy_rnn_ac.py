@@ -15,6 +15,8 @@ never synchronises with the host; every step is a [B, 9]x[9, 3H] + [B, H]x[H, 3H
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -27,15 +29,20 @@ _CAST_CACHE = {}
 def _cast_cached(p, dtype):
     """p.to(dtype) for inference, computed once per parameter VERSION: the rollout calls the policy
     hundreds of times between two optimizer steps, and an optimizer step bumps `p._version` (in-place
-    update), which invalidates the entry.  (14 cast kernels per rollout step otherwise.)"""
+    update), which invalidates the entry.  (14 cast kernels per rollout step otherwise.)
+    An entry belongs to one live Parameter object: it holds a weak reference to it and is dropped when
+    the parameter dies (CPython reuses the id of a freed object - a second model built after the first
+    was freed must not inherit its casts), and it is only valid for the same storage, shape and device."""
     if p.dtype == dtype:
         return p
     key = (id(p), dtype)
     hit = _CAST_CACHE.get(key)
-    if hit is not None and hit[0] == p._version and hit[1].device == p.device:
-        return hit[1]
+    if (hit is not None and hit[0]() is p and hit[1] == p._version and hit[2] == p.data_ptr()
+            and hit[3].shape == p.shape and hit[3].device == p.device):
+        return hit[3]
     t = p.detach().to(dtype)
-    _CAST_CACHE[key] = (p._version, t)
+    ref = weakref.ref(p, lambda _r, k=key: _CAST_CACHE.pop(k, None))
+    _CAST_CACHE[key] = (ref, p._version, p.data_ptr(), t)
     return t
 
 

@@ -97,8 +97,16 @@ class post_train:
             ep_ret += rew[:, 0].double()                                   # r[0] (post_train.py:82)
             ep_len += 1
             ended = done.bool().any(dim=1) | (ep_len == self.max_ep_len) | fin.bool().all(dim=1)
-            if check_domain and (env.error_flags() & 2):
-                raise ValueError("math domain error")  # the reference's drone_step raised here
+            if check_domain:
+                # ONE read of the (read-and-clear) error word per step; both bits are acted on here, so
+                # nothing is lost to the clear.  With E > 1 the word is not attributed to an env: the
+                # whole evaluation aborts, where the reference's sequential loop (E = 1) loses the one
+                # episode it was in - evaluate with E = 1 for the reference's exact abort semantics.
+                flags = env.error_flags()
+                if flags & 2:
+                    raise ValueError("math domain error")  # the reference's drone_step raised here
+                if flags & 1:
+                    raise ValueError("observation contains NaN/Inf")  # ir_gym.py:232-239
             if bool(ended.any()):
                 arrived = info.bool().all(dim=1)
                 success = fin.bool().all(dim=1)

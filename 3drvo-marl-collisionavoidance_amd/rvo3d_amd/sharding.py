@@ -1,10 +1,15 @@
 """Multi-GPU plumbing: environments are independent (no cross-env term anywhere in
 the step), so the path shards with NO data-path collective.
 
-One process per GPU owns `envs_per_rank` environments with its own seed stream;
-the only collectives are the timing barrier and a MAX over the ranks' elapsed
-time (bench.py).  These helpers are backend-agnostic (nccl = RCCL on the GPU
-node, gloo in the CPU tests).
+One process per GPU owns `envs_per_rank` environments with its own seed stream.
+The env step itself never communicates; the collectives of the design are
+  * the PPO update's ONE all-reduce of the flattened gradient bucket per optimizer
+    step, the KL estimate in its last slot (policy/multi_ppo.py: _allreduce_grads),
+    which bench.py --gpus N > 1 also issues inside every timed step;
+  * bench.py's timing barrier, the MAX over the ranks' elapsed time and the
+    all-reduce of ones that counts the ranks (`ranks_seen`).
+These helpers are backend-agnostic (nccl = RCCL on the GPU node, gloo in the CPU
+tests).
 """
 from __future__ import annotations
 

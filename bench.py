@@ -59,16 +59,38 @@ def algorithmic_bytes_per_drone_step(nm: int, nb: int, N: int) -> float:
     return 359.0 + 36.0 * nm + 32.0 * nb / N
 
 
+def usable_cpus():
+    """CPUs this process can really use: min(affinity mask, cgroup CPU quota).  On a shared host the
+    affinity mask shows every hardware thread while the container's quota (cpu.max, cgroup v2; cfs_quota
+    for v1) allows far fewer: running OpenMP over the mask then oversubscribes the quota."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return n, aff, quota
+
+
 def cpu_baseline(N, nm, map_size, seconds_target=12.0):
     """The oracle (kind 'port') on this host, same generator, E scaled down: one thread (the
     scalar port) and every core this process may run on (OpenMP over envs)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc  # test infrastructure, used here only as the timed CPU baseline
     from rvo3d_amd import synthetic_actions, synthetic_world
-    ncpu = len(os.sched_getaffinity(0))
+    ncpu, affinity, quota = usable_cpus()
     recs = {}
-    # 1 thread, the GPU box's per-GPU CPU share (16) and every cpu the process may run on: on a
-    # shared host the last can be slower than the share (oversubscription); the best is reported
+    # 1 thread, the GPU box's per-GPU CPU share (16) and every cpu the process can really use
+    # (min(affinity, cgroup quota)); the best is reported
     for threads in sorted({1, min(ncpu, 16), ncpu}):
         E = 64 if threads == 1 else max(64, 4 * threads)  # several envs per thread
         w = synthetic_world(E, N, map_size)
@@ -87,10 +109,12 @@ def cpu_baseline(N, nm, map_size, seconds_target=12.0):
     one = recs[1]
     return {"value": round(best["value"], 1), "unit": "drone-steps/s", "cores": best["cores"],
             "kind": "port", "value_1core": round(one["value"], 1), "nproc": ncpu,
+            "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
             "by_threads": {str(k): round(v["value"], 1) for k, v in sorted(recs.items())},
             "sample": f"{N} drones x {best['envs']} envs x {best['steps']} fused steps on {best['cores']} threads "
                       f"(oracle/rvo3d_oracle.c, OpenMP over envs); 1 thread: {N} drones x {one['envs']} envs x "
-                      f"{one['steps']} steps = {one['value']:.0f}/s; this process may use {ncpu} cpus"}
+                      f"{one['steps']} steps = {one['value']:.0f}/s; this process can use {ncpu} cpus "
+                      f"(affinity {affinity}, cgroup quota {quota})"}
 
 
 class GradBucket:
@@ -129,7 +153,7 @@ class GradBucket:
         return int(round(float(t.item())))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -155,8 +179,138 @@ def main():
                     "rehearse the N > 1 code path where the ranks cannot have a GPU each)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this one GPU (needs --backend gloo)")
-    args = ap.parse_args()
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the cache-cold kernel timing (roofline.frac_cold)")
+    ap.add_argument("--cold-mb", type=int, default=1024,
+                    help="bytes (MiB) of scratch streamed between two timed launches of the cold measurement "
+                         "(>= 512: twice the 256 MiB Infinity Cache, so state and observation lines are evicted)")
+    ap.add_argument("--no-rollout", action="store_true",
+                    help="skip the `rollout` block (BASELINE config 3 as written: policy forward -> env step -> "
+                         "buffer stores, GAE, one PPO update), which runs after the headline timed region")
+    ap.add_argument("--rollout-steps", type=int, default=16)
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="seconds the launcher (--gpus N > 1 without WORLD_SIZE) waits for its ranks")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="N > 1 plumbing only (rendezvous, ranks_seen all-reduce, JSON relay, exit status); no env "
+                         "step, no GPU: what the CPU test drives with --backend gloo")
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): this process
+    starts the N ranks itself - child processes of this very script with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one per GPU - relays rank 0's JSON line and exits with the ranks' status.  It never
+    touches the GPU (no HIP call; torch.cuda.device_count() does not initialise it) and replaces no
+    process.  The line is refused (exit 3) unless it says n_gpus == N == the ranks an all-reduce saw
+    (the reference's intent: train/policy/multi_ppo.py:179-181, 320-325)."""
+    import subprocess
+    N = args.gpus
+    if not args.launcher_selftest and args.all_ranks_on_device is None:
+        have = torch.cuda.device_count()
+        if have < N:
+            print(f"bench.py: --gpus {N} but this node shows {have} GPU(s): refusing to report fewer ranks "
+                  "than asked for", file=sys.stderr)
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(N):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.launch_timeout
+    rc, out0 = 0, ""
+    try:
+        # rank 0's pipe is drained by communicate(); the others are polled so that one failed rank
+        # ends the job instead of leaving the rest in a collective
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(out=procs[0].communicate()[0]), daemon=True)
+        th.start()
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                rc = next(c for c in codes if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                print("bench.py: the ranks did not finish in --launch-timeout seconds", file=sys.stderr)
+                rc = 124
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:  # exactly the processes started above
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    th.join(timeout=20)
+    out0 = box.get("out") or ""
+    line = next((l for l in reversed(out0.splitlines()) if l.startswith("{")), None)
+    if rc == 0 and line is None:
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 3
+    if line is not None:
+        try:
+            rec = json.loads(line)
+            seen = (rec.get("collective") or {}).get("ranks_seen")
+            if rc == 0 and not (rec.get("n_gpus") == N and seen == N):
+                print(f"bench.py: asked for {N} ranks, the line says n_gpus {rec.get('n_gpus')}, "
+                      f"ranks_seen {seen}", file=sys.stderr)
+                rc = 3
+            rec["launcher"] = "bench.py started the ranks itself (one child process per GPU)"
+            line = json.dumps(rec)
+        except ValueError:
+            rc = rc or 3
+        print(line, flush=True)
+    return rc
+
+
+def selftest_rank(args):
+    """--launcher-selftest: the N > 1 plumbing without the env step (no GPU needed): rendezvous,
+    ranks_seen from a real all-reduce, rank 0's JSON line."""
+    from rvo3d_amd import sharding
+    rank, local_rank, world = sharding.rank_info()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "nccl":
+        raise SystemExit("--launcher-selftest runs on the CPU: use --backend gloo")
+    dist = sharding.init_process_group(args.backend) if world > 1 else None
+    seen = int(round(sharding.sum_over_ranks(dist, 1.0)))
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "drone-steps/sec (env.step throughput)", "value": None, "selftest": True,
+                          "n_gpus": seen, "local_ranks": world,
+                          "collective": {"ranks_seen": seen, "backend": args.backend}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if seen == args.gpus else 3
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    if args.launcher_selftest:
+        return selftest_rank(args)
+    return run_rank(args)
+
+
+def run_rank(args):
     from rvo3d_amd import BatchedDroneEnv, _lib, sharding, synthetic_actions, synthetic_world
 
     # The product library has no diagnostics (no phase ablation, no stamps, reads no environment
@@ -166,7 +320,7 @@ def main():
         raise SystemExit("bench.py refuses the diagnostics build of the library (use tools/bench_diag.py)")
 
     rank, local_rank, world = sharding.rank_info()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:  # (a launcher-less --gpus N > 1 never gets here: main() starts the ranks)
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     dev_index = local_rank if args.all_ranks_on_device is None else args.all_ranks_on_device
@@ -235,16 +389,34 @@ def main():
 
     # kernel time: HIP events on the launch stream (torch's current stream), one pair per launch
     stream = torch.cuda.current_stream(dev)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(K)]
-    for t, (a, b) in enumerate(evs):
-        a.record(stream)
-        env.step(acts[(W + t) % n_act], autoreset=autoreset)
-        b.record(stream)
-    torch.cuda.synchronize()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    def timed_launches(between=None):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        for t, (a, b) in enumerate(evs):
+            if between is not None:
+                between()  # same stream, outside the event pair
+            a.record(stream)
+            env.step(acts[(W + t) % n_act], autoreset=autoreset)
+            b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    kern_ms = timed_launches()
+    # cache-cold: back-to-back launches find the ~54 MB of state the previous launch wrote still in the
+    # 256 MiB Infinity Cache; a trainer runs policy GEMMs over several hundred MB between two env steps.
+    # Here a scratch buffer of --cold-mb MiB is read and rewritten between two timed launches.
+    kern_cold_ms = None
+    if not args.no_cold:
+        scratch = torch.zeros(max(args.cold_mb, 1) << 20, dtype=torch.uint8, device=dev)
+        kern_cold_ms = timed_launches(lambda: scratch.add_(1))
+        del scratch
     flags = env.error_flags()
     coll = None
+    ranks_seen = 1
+    if world > 1:  # from a real all-reduce, whatever else is switched off
+        ones = torch.ones(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_seen = int(round(float(ones.item())))
     if bucket is not None:  # the collective alone, same stream, K repetitions
         ce = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         for a, b in ce:
@@ -252,13 +424,21 @@ def main():
             bucket.step()
             b.record(stream)
         torch.cuda.synchronize()
-        coll = dict(ranks_seen=bucket.ranks_seen(),
+        coll = dict(ranks_seen=ranks_seen,
                     backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none (1 rank)",
                     allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
                     overlapped=side is not None,
                     bucket_bytes=bucket.nbytes, per_step="ONE all-reduce of the gradient bucket with the KL estimate in its last slot "
                     "(multi_ppo._allreduce_grads), once per timed env step")
+    elif world > 1:
+        coll = dict(ranks_seen=ranks_seen, backend="nccl (RCCL)" if args.backend == "nccl" else args.backend,
+                    per_step="none (--no-grad-allreduce)")
 
+    rollout = None
+    if not args.no_rollout and rank == 0 and world == 1:
+        rollout = rollout_block(env, args)
+
+    status = 0
     if rank == 0:
         total_units = world * E * N * K
         value = total_units / elapsed
@@ -280,7 +460,7 @@ def main():
                 traffic = None
         out = {
             "metric": "drone-steps/sec (env.step throughput)",
-            "value": round(value, 1), "unit": "drone-steps/s", "n_gpus": world, "steps": K,
+            "value": round(value, 1), "unit": "drone-steps/s", "n_gpus": ranks_seen, "steps": K,
             "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 3 env.step: {N} drones x {E} envs per GPU, "
@@ -296,28 +476,76 @@ def main():
                          "fp64_valu_tflops": (round(fp64_flops / (kern_ms * 1e-3) / 1e12, 3)
                                               if fp64_flops else None),
                          "fp64_valu_peak_tflops": 78.6,
-                         "kernel": "rvo3d::env_kernel<%d, %d, %d, true> (fused step%s)" % (
-                             2 if autoreset else 1, 1 if N <= 64 else 2 if N <= 128 else 4 if N <= 256 else 8,
-                             N if N in (16, 32, 64, 128, 256) and env.launch_info()["envs_per_block"] == max(64 // N, 1) else 0,
-                             " + auto-reset" if autoreset else ""),
+                         # the instantiation the library launches for this handle (rvo3d_kernel_name)
+                         "kernel": env.kernel_name("step_autoreset" if autoreset else "step"),
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_drone_step": B},
         }
+        if kern_cold_ms is not None:
+            ach_cold = bytes_per_launch / (kern_cold_ms * 1e-3) / 1e9
+            out["roofline"].update({
+                "kernel_ms_cold": round(kern_cold_ms, 4), "achieved_cold": round(ach_cold, 2),
+                "frac_cold": round(ach_cold / HBM_PEAK_GBS, 5),
+                "cold": f"{args.cold_mb} MiB of scratch read and rewritten on the launch stream between two "
+                        "timed launches (outside the event pairs): nothing of the previous step is left in "
+                        "the 256 MiB Infinity Cache - the regime of a rollout with policy GEMMs between env steps"})
         if coll is not None:
-            coll["value_env_step_only"] = round(total_units / elapsed_step_only, 1)
-            coll["ms_per_step_env_step_only"] = round(elapsed_step_only / K * 1e3, 4)
+            if elapsed_step_only is not None:
+                coll["value_env_step_only"] = round(total_units / elapsed_step_only, 1)
+                coll["ms_per_step_env_step_only"] = round(elapsed_step_only / K * 1e3, 4)
+                out["config"]["workload"] += ("; + gradient-bucket all-reduce and KL mean per step" +
+                                              (" on a second stream" if side is not None else ""))
             out["collective"] = coll
-            out["config"]["workload"] += ("; + gradient-bucket all-reduce and KL mean per step" +
-                                          (" on a second stream" if side is not None else ""))
+        if rollout is not None:
+            out["rollout"] = rollout
         if not args.no_cpu_baseline and world == 1:  # reported once, at N = 1
             out["cpu_baseline"] = cpu_baseline(N, nm, tuple(args.map))
+        if ranks_seen != args.gpus:
+            out["error"] = f"--gpus {args.gpus} but the all-reduce saw {ranks_seen} rank(s)"
+            status = 3
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return status
+
+
+def rollout_block(env, args):
+    """BASELINE config 3 AS WRITTEN - "full MA-PPO rollout + update, MLP(256,256) policy" - measured
+    after the headline region, on the same env: T rollout steps of the trainer's own loop
+    (rvo3d_amd.policy.multi_ppo.collect: policy forward in bf16 -> env step from the policy samples ->
+    buffer stores; reference loop: train/policy/multi_ppo.py:183-281), one GAE scan and one clipped-PPO
+    update of 2 + 2 optimizer iterations over the T * E * N samples (reference: :341-376).  Reported
+    beside the headline, never as `value`."""
+    from rvo3d_amd.policy import mlp_ac, multi_ppo
+    T, E, N = args.rollout_steps, env.E, env.N
+    dev = env.device
+    try:
+        ac = mlp_ac(env.W).to(dev)
+        tr = multi_ppo(env, ac, train_epoch=0, steps_per_epoch=T, max_ep_len=500, train_pi_iters=2,
+                       train_v_iters=2, target_kl=1e9, minibatch_size=E * N, save_freq=10 ** 9, amp=True)
+        env.reset(); env.observe()
+        tr.collect(); tr.buf.get()  # warm-up: allocator, hipBLASLt heuristics
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tr.collect()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        data = tr.buf.get()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        tr.update(data)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        rec = {"workload": f"{N} drones x {E} envs, MLP(256,256) actor-critic, bf16 policy GEMMs, T = {T} steps; "
+                           "update = 2 policy + 2 value iterations, minibatch E*N",
+               "drone_steps_per_s": round(E * N * T / (t1 - t0), 1),
+               "ms_per_step": round((t1 - t0) / T * 1e3, 4),
+               "gae_ms": round((t2 - t1) * 1e3, 3), "update_s": round(t3 - t2, 4),
+               "update_samples_per_s": round(E * N * T * 4 / (t3 - t2), 1)}
+        rec.update(tr.rollout_profile())  # env_kernel_us, launches_per_step (None when not measurable)
+        return rec
+    except Exception as ex:  # the headline must not die with the secondary measurement
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

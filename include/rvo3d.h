@@ -185,6 +185,12 @@ int rvo3d_error_flags(rvo3d_env *h, uint32_t *flags, void *stream);
 int rvo3d_launch_info(rvo3d_env *h, int32_t *threads, int32_t *envs_per_block,
                       int32_t *blocks, int32_t *lds_bytes);
 
+/* The kernel instantiation this handle's calls launch, as rocprofv3 names it
+ * ("rvo3d::env_kernel<MODE, NW, NFIX, TRAIN>"; mode 0 = rvo3d_observe, 1 = rvo3d_step,
+ * 2 = rvo3d_step_autoreset / rvo3d_step_policy with autoreset), written to buf (HOST, cap bytes,
+ * NUL-terminated): bench.py's roofline.kernel. */
+int rvo3d_kernel_name(rvo3d_env *h, int32_t mode, char *buf, int32_t cap);
+
 /* (Diagnostics - phase stamps, phase ablation - are not part of this library: they exist
  * only in the -DRVO3D_DIAG build that tools/ makes for itself, include/rvo3d_diag.h.) */
 

@@ -311,3 +311,113 @@ def test_gradient_allreduce_keeps_ranks_identical():
         p.join(timeout=60)
         assert p.exitcode == 0
     np.testing.assert_array_equal(out[0], out[1])
+
+
+def test_cast_cache_is_tied_to_the_parameter_object():
+    """the bf16 weight cache was keyed on id(p) + version; CPython reuses the id of a freed
+    Parameter, so a second model built after the first one was freed got the first one's weights."""
+    from rvo3d_amd.policy import policy_rnn_ac as P
+    stale = 0
+    for i in range(40):  # sequentially created and freed: ids are reused
+        p = torch.nn.Parameter(torch.full((4, 4), float(i)))
+        c = P._cast_cached(p, torch.bfloat16)
+        stale += int(not torch.equal(c.float(), p.detach()))
+        del p, c
+    assert stale == 0
+    assert len(P._CAST_CACHE) <= 1  # entries die with their parameter
+    # same object: cached until its version (in-place update) or its storage changes
+    p = torch.nn.Parameter(torch.ones(3))
+    c0 = P._cast_cached(p, torch.bfloat16)
+    assert P._cast_cached(p, torch.bfloat16) is c0
+    with torch.no_grad():
+        p.add_(1.0)
+    assert torch.equal(P._cast_cached(p, torch.bfloat16).float(), torch.full((3,), 2.0))
+    p.data = torch.full((3,), 5.0)  # what module.to(...) / load with assign do: new storage, same object
+    assert torch.equal(P._cast_cached(p, torch.bfloat16).float(), torch.full((3,), 5.0))
+
+
+def test_two_models_in_a_row_under_the_cached_inference_path(monkeypatch):
+    """The cached bf16 inference path (mlp_ac.step_tensors under autocast) against the uncached module
+    forward, for two models built one after the other in one process."""
+    monkeypatch.setattr(torch, "is_autocast_enabled", lambda *a: True)
+    for seed in (1, 2, 3):
+        torch.manual_seed(seed)
+        ac = mlp_ac(102)
+        x = torch.randn(32, 102)
+        mu = ac._fused_forward(ac.pi_net, x.to(torch.bfloat16)).float()
+        ref = ac.pi_net.to(torch.bfloat16)(x.to(torch.bfloat16)).float()
+        assert torch.allclose(mu, ref, atol=2e-2), seed
+        del ac
+
+
+def _shard_data(rank, n=64):
+    g = torch.Generator().manual_seed(100 + rank)
+    return dict(obs=torch.randn(n, 21, generator=g), act=torch.randn(n, 3, generator=g) * 0.3,
+                adv=torch.randn(n, generator=g), ret=torch.randn(n, generator=g),
+                logp=torch.randn(n, generator=g) * 0.1 - 2.0)
+
+
+def _order_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group("gloo")
+    torch.manual_seed(0)
+    ac = mlp_ac(21, hidden_sizes=(16, 16))
+    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, train_pi_iters=2, train_v_iters=1, target_kl=1e9,
+                   use_gpu=False, dist=dist, seed=5, reference_order=True, max_update_num=2)
+    np.random.seed(1000 + rank)            # somebody else uses numpy's global generator, differently
+    np.random.rand(rank + 3)               # on every rank: the agent order must not care
+    noise = float(torch.randn(1))          # action noise differs between the shards (seed + rank)
+    agents = [_shard_data(10 * rank + k, n=16) for k in range(4)]
+    st = tr.update(agents)                 # the reference's own signature: one dict per agent
+    w = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()
+    q.put((rank, (st["order"], noise, w)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_order_is_the_same_on_every_rank_and_noise_is_not():
+    """the shuffled agent order must not depend on the process-global numpy generator
+    (ranks that drew different orders would average gradients of different agents, silently), and the
+    sampling noise must differ between the shards."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (o0, n0, w0), (o1, n1, w1) = out[0], out[1]
+    assert o0 == o1 and sorted(o0) == [0, 1, 2, 3]
+    ref = np.arange(4)
+    np.random.RandomState(5).shuffle(ref)  # = np.random.seed(5); np.random.shuffle (the reference)
+    assert o0 == [int(x) for x in ref]
+    assert n0 != n1
+    np.testing.assert_array_equal(w0, w1)
+
+
+def test_two_rank_update_equals_one_rank_on_the_concatenated_data():
+    """Mean of the two shards' gradients = gradient of the mean over both shards (equal shards): the
+    pooled update on 2 ranks ends where a single process ends on the concatenated samples."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ac = mlp_ac(21, hidden_sizes=(16, 16))
+    tr = multi_ppo(_FakeEnv(), ac, steps_per_epoch=2, train_pi_iters=3, train_v_iters=2, target_kl=1e9,
+                   use_gpu=False, seed=0)
+    both = [_shard_data(0), _shard_data(1)]
+    tr.update({k: torch.cat([d[k] for d in both]) for k in both[0]})
+    one = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()
+    np.testing.assert_allclose(out[0], one, rtol=2e-5, atol=2e-6)
