@@ -184,6 +184,9 @@ def parse_args(argv=None):
     ap.add_argument("--cold-mb", type=int, default=1024,
                     help="bytes (MiB) of scratch streamed between two timed launches of the cold measurement "
                          "(>= 512: twice the 256 MiB Infinity Cache, so state and observation lines are evicted)")
+    ap.add_argument("--cold-mode", default="rw", choices=["rw", "read"],
+                    help="rw: the scratch is read and rewritten (the cache is left full of dirty lines, as after "
+                         "the policy GEMMs of a rollout); read: only read (clean lines)")
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the `rollout` block (BASELINE config 3 as written: policy forward -> env step -> "
                          "buffer stores, GAE, one PPO update), which runs after the headline timed region")
@@ -408,7 +411,7 @@ def run_rank(args):
     kern_cold_ms = None
     if not args.no_cold:
         scratch = torch.zeros(max(args.cold_mb, 1) << 20, dtype=torch.uint8, device=dev)
-        kern_cold_ms = timed_launches(lambda: scratch.add_(1))
+        kern_cold_ms = timed_launches((lambda: scratch.add_(1)) if args.cold_mode == "rw" else (lambda: scratch.sum()))
         del scratch
     flags = env.error_flags()
     coll = None
@@ -487,7 +490,7 @@ def run_rank(args):
             out["roofline"].update({
                 "kernel_ms_cold": round(kern_cold_ms, 4), "achieved_cold": round(ach_cold, 2),
                 "frac_cold": round(ach_cold / HBM_PEAK_GBS, 5),
-                "cold": f"{args.cold_mb} MiB of scratch read and rewritten on the launch stream between two "
+                "cold": f"{args.cold_mb} MiB of scratch {'read and rewritten' if args.cold_mode == 'rw' else 'read'} on the launch stream between two "
                         "timed launches (outside the event pairs): nothing of the previous step is left in "
                         "the 256 MiB Infinity Cache - the regime of a rollout with policy GEMMs between env steps"})
         if coll is not None:

@@ -236,3 +236,48 @@ def vo_circle2(env_train, self8, other8, action):
     lib().orc_vo_circle2(int(bool(env_train)), _dp(s8), _dp(o8), _dp(a), _dp(obs), _ip(flag),
                          _dp(t), _ip(col), _dp(md), _ip(dom))
     return obs, bool(flag[0]), float(t[0]), bool(col[0]), float(md[0]), bool(dom[0])
+
+
+# ---- reciprocal_vel_obs, call by call (the methods of the class that run on an instance) ----
+def rvo_distance(p1, p2):
+    L = lib()
+    L.orc_rvo_distance.restype = C.c_double
+    a, b = (np.ascontiguousarray(x, dtype=np.float64) for x in (p1, p2))
+    return float(L.orc_rvo_distance(_dp(a), _dp(b)))
+
+
+def rvo_preprocess(agent3, drones, buildings):
+    """reciprocal_vel_obs.preprocess: (keep_drone[n], keep_building[nb]) as bool arrays."""
+    a = np.ascontiguousarray(agent3, dtype=np.float64)
+    d = np.ascontiguousarray(np.asarray(drones, dtype=np.float64).reshape(-1, 3))
+    b = np.ascontiguousarray(np.asarray(buildings, dtype=np.float64).reshape(-1, 4))
+    kd, kb = np.zeros(len(d), np.uint8), np.zeros(len(b), np.uint8)
+    lib().orc_rvo_preprocess(_dp(a), _dp(d), len(d), _dp(b), len(b), _bp(kd), _bp(kb))
+    return kd.astype(bool), kb.astype(bool)
+
+
+def rvo_penalty(vel, vel_des, agent8, odro8, factor=1.0):
+    L = lib()
+    L.orc_rvo_penalty.restype = C.c_double
+    L.orc_rvo_penalty.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_double]
+    v, vd, a = (np.ascontiguousarray(x, dtype=np.float64) for x in (vel, vel_des, agent8))
+    o = np.ascontiguousarray(np.asarray(odro8, dtype=np.float64).reshape(-1, 8))
+    return float(L.orc_rvo_penalty(_dp(v), _dp(vd), _dp(a), _dp(o), len(o), float(factor)))
+
+
+def rvo_candidates(vel3, vmax, acceler):
+    L = lib()
+    L.orc_rvo_candidates.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+    v, vm = (np.ascontiguousarray(x, dtype=np.float64) for x in (vel3, vmax))
+    out = np.zeros((512, 3))
+    n = L.orc_rvo_candidates(_dp(v), _dp(vm), float(acceler), _dp(out), 512)
+    return out[:n].copy()
+
+
+def rvo_select_inside(inside, agent11, odro8):
+    L = lib()
+    L.orc_rvo_select_inside.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    ins = np.ascontiguousarray(np.asarray(inside, dtype=np.float64).reshape(-1, 3))
+    a = np.ascontiguousarray(agent11, dtype=np.float64)
+    o = np.ascontiguousarray(np.asarray(odro8, dtype=np.float64).reshape(-1, 8))
+    return int(L.orc_rvo_select_inside(_dp(ins), len(ins), _dp(a), _dp(o), len(o)))

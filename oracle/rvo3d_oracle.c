@@ -880,75 +880,172 @@ static double arange_at(double lo, int k) {
   return lo + k * (next - lo);
 }
 
+/* ---- the parts of reciprocal_vel_obs that DO run on an instance, one function each; orc_rvo_vel
+ * below is built from exactly these, and tests/golden/rvo_calls.npz (oracle/gen_golden_rvo.py) holds
+ * what the reference's own methods return for the same arguments. ---- */
+
+/* reciprocal_vel_obs.distance (reciprocal_vel_obs.py:149-151) */
+double orc_rvo_distance(const double *p1, const double *p2) {
+  return sqrt(sq(p2[0] - p1[0]) + sq(p2[1] - p1[1]) + sq(p2[2] - p1[2]));
+}
+
+/* reciprocal_vel_obs.preprocess (:32-54): neighbours with np.linalg.norm(agent - drone) <= 10 (no
+ * self-exclusion: the caller passes the others), buildings [x, y, h, r] with h > z - 1 and
+ * np.linalg.norm(xy - bxy) <= 10 (this class's own gate: not rvo_inter's z - 2 / 5 m).  The
+ * building list is computed and then dropped by cal_vel (:22-25): it never reaches a velocity. */
+void orc_rvo_preprocess(const double *agent3, const double *drones /* [n][3] */, int n,
+                        const double *blds /* [nb][4] */, int nb, uint8_t *keep_drone,
+                        uint8_t *keep_bld) {
+  for (int j = 0; j < n; ++j) {
+    const double *pb = drones + 3 * (size_t)j;
+    double dif[3] = {agent3[0] - pb[0], agent3[1] - pb[1], agent3[2] - pb[2]};
+    keep_drone[j] = norm3_blas(dif) <= 10;
+  }
+  for (int b = 0; b < nb; ++b) {
+    const double *B = blds + 4 * (size_t)b;
+    keep_bld[b] = (B[2] > agent3[2] - 1) && (norm2_blas(agent3[0] - B[0], agent3[1] - B[1]) <= 10);
+  }
+}
+
+/* min(tc_list) of reciprocal_vel_obs.penalty (:126-143) over the records odro8 [n][8] =
+ * [p(3), v(3), r, prio]; n >= 1 (the reference's min() of an empty list raises). */
+static double rvo_tc_min(const double *agent8, const double *odro8, int n) {
+  double tc_min = INFINITY;
+  for (int j = 0; j < n; ++j) {
+    const double *o = odro8 + 8 * (size_t)j;
+    double tc = cal_exp_tim_classic(agent8, o, agent8 + 3, o + 3, agent8[6], o[6]);
+    if (j == 0 || tc < tc_min) tc_min = tc;  /* Python min: the first of equal values */
+  }
+  return tc_min;
+}
+/* reciprocal_vel_obs.penalty (:126-147): factor * 1 / tc_min (inf when tc_min == 0) + distance(vel_des, vel) */
+double orc_rvo_penalty(const double *vel, const double *vel_des, const double *agent8,
+                       const double *odro8, int n, double factor) {
+  double tc_min = rvo_tc_min(agent8, odro8, n);
+  double tc_inv = (tc_min == 0) ? INFINITY : 1 / tc_min;
+  return factor * tc_inv + orc_rvo_distance(vel_des, vel);
+}
+
+/* The candidate grid of reciprocal_vel_obs.vel_candidate (:85-101): np.arange over
+ * np.clip([v - acceler, v + acceler], -vmax, vmax) per axis in steps of 0.5, |v| >= 0.3 (with an
+ * empty VO list the method runs and returns exactly this list as vo_outside).  Returns the count;
+ * out [cap][3] in the method's order (x outermost). */
 #define ORC_RVO_MAXC 512
+int orc_rvo_candidates(const double *vel3, const double *vmax, double acceler, double *out, int cap) {
+  double lo[3], hi[3];
+  int cnt[3], n = 0;
+  for (int k = 0; k < 3; ++k) {
+    lo[k] = clampd(vel3[k] - acceler, -vmax[k], vmax[k]);  /* np.clip */
+    hi[k] = clampd(vel3[k] + acceler, -vmax[k], vmax[k]);
+    cnt[k] = arange_len(lo[k], hi[k]);
+  }
+  for (int ix = 0; ix < cnt[0] && ix < ORC_RVO_MAXC; ++ix)
+    for (int iy = 0; iy < cnt[1] && iy < ORC_RVO_MAXC; ++iy)
+      for (int iz = 0; iz < cnt[2] && iz < ORC_RVO_MAXC; ++iz) {
+        const double v[3] = {arange_at(lo[0], ix), arange_at(lo[1], iy), arange_at(lo[2], iz)};
+        if (sqrt(sq(v[0]) + sq(v[1]) + sq(v[2])) < 0.3) continue;
+        if (n < cap) memcpy(out + 3 * (size_t)n, v, sizeof v);
+        ++n;
+      }
+  return n;
+}
+
+/* reciprocal_vel_obs.vel_select (:119-124) when vo_outside is empty - the one branch of it that
+ * returns: min(vo_inside, key=penalty), the first of equal minima.  Returns the index, -1 if n_in == 0. */
+int orc_rvo_select_inside(const double *inside /* [n_in][3] */, int n_in, const double *agent11,
+                          const double *odro8, int n) {
+  int best = -1;
+  double bp = 0;
+  for (int k = 0; k < n_in; ++k) {
+    double p = orc_rvo_penalty(inside + 3 * (size_t)k, agent11 + 8, agent11, odro8, n, 1);
+    if (best < 0 || p < bp) { best = k; bp = p; }
+  }
+  return best;
+}
+
+/* cal_vel (:19-31) for every drone.  Built from the functions above; what no running reference
+ * method covers - config_vo (:63-83 raises: state[0:4] has four values for get_PAA's three),
+ * vo_out2 (:103-117 raises: list.append assignment) and the vo_outside branch of vel_select
+ * (returns None) - is the algorithm those lines spell out on the reference's helper functions
+ * (get_alpha / get_PAA / get_rvo_array / get_beta, pinned by tests/golden/rvo_vel.npz).
+ * Margin audit: the two roundings that rest on libm results (alpha = round(asin), beta =
+ * round(acos)) report their distance to a tie per agent, as the step's decisions do. */
 void orc_rvo_vel(const orc_env *h, const double *vmax, double acceler, double *out) {
   const int N = h->N;
+  for (int g = 0; g < h->E * N; ++g) h->margin[g] = INFINITY;
 #pragma omp parallel for schedule(static) num_threads(h->threads)
   for (int g = 0; g < h->E * N; ++g) {
-    tl_margin = 0; tl_site = 0;  /* no audit here: never a stale pointer of an earlier env */
+    tl_margin = 0; tl_site = 0;
     const int e = g / N;
     const double *pa = h->p + 3 * (size_t)g, *va = h->v + 3 * (size_t)g;
     const double ra = h->radius[g], pra = h->prio[g];
-    double des[3];
-    cal_des_vel(pa, wp_at(h, g, h->wp_idx[g]), des);
-    double lo[3], hi[3];
-    int cnt[3];
-    for (int k = 0; k < 3; ++k) {
-      lo[k] = clampd(va[k] - acceler, -vmax[k], vmax[k]);  /* np.clip */
-      hi[k] = clampd(va[k] + acceler, -vmax[k], vmax[k]);
-      cnt[k] = arange_len(lo[k], hi[k]);
-    }
-    double best_out = INFINITY, best_in = INFINITY;
-    double sel_out[3] = {0, 0, 0}, sel_in[3] = {0, 0, 0};
-    int have_out = 0, have_in = 0;
-    /* tc_min over the neighbours in range (penalty, :126-147) */
-    double tc_min = INFINITY;
+    double agent[11] = {pa[0], pa[1], pa[2], va[0], va[1], va[2], ra, pra, 0, 0, 0};
+    cal_des_vel(pa, wp_at(h, g, h->wp_idx[g]), agent + 8);
+    const double *des = agent + 8;
+    /* preprocess: the other drones of the env within 10 m, as 8-value records */
+    double *others = (double *)malloc(sizeof(double) * 3 * (size_t)N);
+    uint8_t *keep = (uint8_t *)malloc((size_t)N);
+    double *odro = (double *)malloc(sizeof(double) * 8 * (size_t)N);
+    int no = 0;
+    for (int j = 0; j < N; ++j) memcpy(others + 3 * (size_t)j, h->p + 3 * (size_t)(e * N + j), 3 * sizeof(double));
+    orc_rvo_preprocess(pa, others, N, 0, 0, keep, 0);
     for (int j = 0; j < N; ++j) {
       const int gj = e * N + j;
-      if (gj == g) continue;
-      const double *pb = h->p + 3 * (size_t)gj;
-      double dif[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-      if (!(norm3_blas(dif) <= 10)) continue;
-      double tc = cal_exp_tim_classic(pa, pb, va, h->v + 3 * (size_t)gj, ra, h->radius[gj]);
-      if (tc < tc_min) tc_min = tc;
+      if (gj == g || !keep[j]) continue;
+      double *o = odro + 8 * (size_t)no++;
+      memcpy(o, h->p + 3 * (size_t)gj, 3 * sizeof(double));
+      memcpy(o + 3, h->v + 3 * (size_t)gj, 3 * sizeof(double));
+      o[6] = h->radius[gj]; o[7] = h->prio[gj];
     }
-    const double tc_inv = (tc_min == 0) ? INFINITY : 1.0 / tc_min;
-    for (int ix = 0; ix < cnt[0] && ix < ORC_RVO_MAXC; ++ix)
-      for (int iy = 0; iy < cnt[1] && iy < ORC_RVO_MAXC; ++iy)
-        for (int iz = 0; iz < cnt[2] && iz < ORC_RVO_MAXC; ++iz) {
-          const double v[3] = {arange_at(lo[0], ix), arange_at(lo[1], iy), arange_at(lo[2], iz)};
-          if (sqrt(sq(v[0]) + sq(v[1]) + sq(v[2])) < 0.3) continue;
-          const double pn[3] = {pa[0] + v[0] * 1, pa[1] + v[1] * 1, pa[2] + v[2] * 1};
-          int inside = 0;
-          for (int j = 0; j < N; ++j) {  /* vo_out2 over the VO list */
-            const int gj = e * N + j;
-            if (gj == g) continue;
-            const double *pb = h->p + 3 * (size_t)gj, *vb = h->v + 3 * (size_t)gj;
-            double dif[3] = {pa[0] - pb[0], pa[1] - pb[1], pa[2] - pb[2]};
-            if (!(norm3_blas(dif) <= 10)) continue;
-            double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-            double q = (ra + h->radius[gj]) / norm3_blas(ab);
-            double alpha = (q <= 1.0) ? orc_py_round2(asin(q)) : 1.57;  /* get_alpha */
-            double pr = pra / (pra + h->prio[gj]);                      /* get_PAA */
-            double paa[3] = {pr * (2 * pa[0] + (va[0] + vb[0]) * 1),
-                             pr * (2 * pa[1] + (va[1] + vb[1]) * 1),
-                             pr * (2 * pa[2] + (va[2] + vb[2]) * 1)};
-            double w[3] = {pn[0] - paa[0], pn[1] - paa[1], pn[2] - paa[2]};
-            double beta = get_beta_classic(ab, w);
-            if (alpha > beta) inside = 1;
-          }
-          const double dd = sqrt(sq(des[0] - v[0]) + sq(des[1] - v[1]) + sq(des[2] - v[2]));
-          if (!inside) {  /* min(vo_outside, key=distance): the first minimum */
-            if (!have_out || dd < best_out) { best_out = dd; memcpy(sel_out, v, sizeof v); have_out = 1; }
-          } else {        /* min(vo_inside, key=penalty) */
-            const double pen = 1 * tc_inv + dd;
-            if (!have_in || pen < best_in) { best_in = pen; memcpy(sel_in, v, sizeof v); have_in = 1; }
-          }
-        }
+    /* config_vo per neighbour (as intended): alpha, PAA, rel */
+    double *vo = (double *)malloc(sizeof(double) * 7 * (size_t)(no > 0 ? no : 1));
+    tl_margin = h->margin + g; tl_site = h->msite + g;
+    for (int j = 0; j < no; ++j) {
+      const double *o = odro + 8 * (size_t)j;
+      double ab[3] = {o[0] - pa[0], o[1] - pa[1], o[2] - pa[2]};
+      double q = (ra + o[6]) / norm3_blas(ab);
+      double alpha = 1.57;
+      if (q <= 1.0) { double as = asin(q); mg_round0(as, 100.0); alpha = orc_py_round2(as); }  /* get_alpha */
+      double pr = pra / (pra + o[7]);                                                          /* get_PAA */
+      double *w = vo + 7 * (size_t)j;
+      w[0] = pr * (2 * pa[0] + (va[0] + o[3]) * 1);
+      w[1] = pr * (2 * pa[1] + (va[1] + o[4]) * 1);
+      w[2] = pr * (2 * pa[2] + (va[2] + o[5]) * 1);
+      w[3] = ab[0]; w[4] = ab[1]; w[5] = ab[2]; w[6] = alpha;
+    }
+    double cand[3 * 125];
+    int nc = orc_rvo_candidates(va, vmax, acceler, cand, 125);
+    if (nc > 125) nc = 125;  /* acceler <= 1: at most 5 per axis */
+    double best_out = INFINITY;
+    int sel_out = -1, n_in = 0;
+    double inside[3 * 125];
+    for (int c = 0; c < nc; ++c) {
+      const double *v = cand + 3 * (size_t)c;
+      const double pn[3] = {pa[0] + v[0] * 1, pa[1] + v[1] * 1, pa[2] + v[2] * 1};
+      int in = 0;
+      for (int j = 0; j < no; ++j) {  /* vo_out2 over the VO list */
+        const double *w = vo + 7 * (size_t)j;
+        double d3[3] = {pn[0] - w[0], pn[1] - w[1], pn[2] - w[2]};
+        double dotp = dot3_blas(w + 3, d3);
+        double AB = norm3_blas(w + 3) * norm3_blas(d3);
+        double cs = (AB != 0) ? dotp / AB : 0.0;
+        double ang = acos(cs);
+        mg_round0(ang, 100.0);
+        if (w[6] > get_beta_classic(w + 3, d3)) in = 1;
+      }
+      if (!in) {  /* min(vo_outside, key=distance(v, vel_des)): the first minimum */
+        const double dd = orc_rvo_distance(v, des);
+        if (sel_out < 0 || dd < best_out) { best_out = dd; sel_out = c; }
+      } else {
+        memcpy(inside + 3 * (size_t)n_in++, v, 3 * sizeof(double));
+      }
+    }
+    tl_margin = 0; tl_site = 0;
     double *o = out + 3 * (size_t)g;
-    if (have_out) memcpy(o, sel_out, sizeof sel_out);
-    else if (have_in) memcpy(o, sel_in, sizeof sel_in);
+    if (sel_out >= 0) memcpy(o, cand + 3 * (size_t)sel_out, 3 * sizeof(double));
+    else if (n_in > 0) memcpy(o, inside + 3 * (size_t)orc_rvo_select_inside(inside, n_in, agent, odro, no), 3 * sizeof(double));
     else o[0] = o[1] = o[2] = 0.0;
+    free(others); free(keep); free(odro); free(vo);
   }
 }
 

@@ -79,6 +79,16 @@ void orc_des_vel(const orc_env *h, double *des_vel);
  * (reciprocal_vel_obs.py:19-166 as intended; the class itself cannot run: PARITY UNPINNED
  * for the driver loop, see the .c).  vmax[3], acceler; out [E*N][3]. */
 void orc_rvo_vel(const orc_env *h, const double *vmax, double acceler, double *out);
+/* The methods of reciprocal_vel_obs that run on an instance (reciprocal_vel_obs.py:32-54, :85-101
+ * with an empty VO list, :119-124 with an empty vo_outside, :126-147, :149-151), call by call:
+ * checked against tests/golden/rvo_calls.npz, which holds the reference's own return values. */
+double orc_rvo_distance(const double *p1, const double *p2);
+void orc_rvo_preprocess(const double *agent3, const double *drones, int n, const double *blds, int nb,
+                        uint8_t *keep_drone, uint8_t *keep_bld);
+double orc_rvo_penalty(const double *vel, const double *vel_des, const double *agent8,
+                       const double *odro8, int n, double factor);
+int orc_rvo_candidates(const double *vel3, const double *vmax, double acceler, double *out, int cap);
+int orc_rvo_select_inside(const double *inside, int n_in, const double *agent11, const double *odro8, int n);
 
 /* Call-level check of rvo_inter.config_vo_inf (rvo_inter.py:20-61) for drone i
  * of env e against the current state, with an arbitrary action.  rows

@@ -25,3 +25,18 @@ def pytest_sessionstart(session):
             os.remove(f)
         except OSError:
             pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The knife-edge accounting of a `-m gpu` run in the run's own output (also under -q), so that
+    whoever ran the suite - the driver at round end included - has the tally of exactly that run:
+    the TOTAL line test_zz_knife_edge_share_over_all_tests computed over every test's record."""
+    import json
+    f = os.path.join(ROOT, "gpurun_out", "parity_tally.json")
+    try:
+        with open(f) as fh:
+            tot = json.load(fh).get("TOTAL")
+    except (OSError, ValueError):
+        return
+    if tot:
+        terminalreporter.write_line("parity tally TOTAL: " + json.dumps(tot, sort_keys=True))

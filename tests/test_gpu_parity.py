@@ -14,9 +14,11 @@ is exempt from the comparison.  The accounting (class Tally):
     ~1/200 per drone-step, observed 0.4-0.6 %); the LAST test of this file bounds the share
     over all tests together at 1 % flat;
   * exempt samples that REALLY differed are counted per sample (knife_mismatch <= knife);
-  * an env in which an exempt sample differed has a different future from then on: it
-    leaves the comparison for the rest of the run (`dropped_envs`), it is not carried
-    along under the exemption;
+  * an env in which an exempt sample differed has a different future from then on.  It is
+    neither carried along under the exemption nor abandoned: its state is RE-SYNCHRONISED -
+    overwritten with the reference's recorded post-step state (golden replays) or the oracle's
+    (`resync_from_oracle`) - counted in `resyncs`, and compared again from the next step on, so
+    every step of every scenario is compared (`steps_compared == steps`);
   * every test's tally is written to gpurun_out/parity_tally.json (copied to
     profiles/rNN/parity_tally.json for the record).
 Everything else must match exactly."""
@@ -60,8 +62,8 @@ class Tally:
 
     def __init__(self, name, E=1, strict=False):
         self.name, self.strict = name, strict
-        self.samples = self.knife = self.knife_mismatch = 0
-        self.dropped = np.zeros(E, bool)   # envs that left the comparison
+        self.samples = self.knife = self.knife_mismatch = self.resyncs = 0
+        self.dropped = np.zeros(E, bool)   # envs whose state has diverged and is not yet re-synchronised
         self.mg = None
         self.bad = None
 
@@ -92,14 +94,40 @@ class Tally:
         self.dropped |= self.bad.any(axis=1)
         return self.dropped
 
+    def resync(self):
+        """The caller has brought the diverged envs back in line with the reference."""
+        self.resyncs += int(self.dropped.sum())
+        self.dropped[:] = False
+
     def finish(self, **extra):
         rec = dict(samples=self.samples, knife=self.knife, knife_mismatch=self.knife_mismatch,
-                   dropped_envs=int(self.dropped.sum()), envs=len(self.dropped), **extra)
+                   dropped_envs=int(self.dropped.sum()), resyncs=self.resyncs, envs=len(self.dropped), **extra)
         _record_tally(self.name, rec)
         lim = KNIFE_SHARE * self.samples
         assert self.knife <= lim + 3.0 * np.sqrt(lim) + 2, rec
         assert self.knife_mismatch <= self.knife, rec
         return rec
+
+
+STATE_KEYS = ("pos", "vel", "yaw", "pitch", "real_len", "max_dev", "extra_len", "wp_idx", "arrive", "dest")
+
+
+def resync_from_oracle(env, ref, tl, extra=None):
+    """Envs in which an exempt sample really differed (tl.dropped), or `extra`: overwrite their
+    device state with the oracle's (all ten arrays) and take them back into the comparison."""
+    d = tl.dropped.copy()
+    if extra is not None:
+        d |= np.asarray(extra, bool)
+    if not d.any():
+        return 0
+    rs = ref.get_state()
+    s = {k: v.cpu().numpy() for k, v in env.get_state().items()}
+    for k in STATE_KEYS:
+        s[k][d] = rs[k][d]
+    env.set_state(**s)
+    tl.dropped |= d
+    tl.resync()
+    return int(d.sum())
 
 
 def close(a, b):
@@ -136,8 +164,6 @@ def test_hip_replays_reference_golden(path):
     T = fx["actions"].shape[0]
     steps_compared = 0
     for t in range(T):
-        if tl.dropped[0]:
-            break  # an exempt sample really differed: the run's future is a different one
         tl.begin(fx["margin"][t])
         if "set_pos" in fx:
             env.set_state(pos=fx["set_pos"][t][None], vel=fx["set_vel"][t][None],
@@ -156,20 +182,29 @@ def test_hip_replays_reference_golden(path):
         tl.check(f"reward t={t}", close(r, fx["reward"][t]))
         tl.check(f"obs f32-exact t={t}", eq_nan(o, fx["obs"][t].astype(np.float32)))
         tl.check(f"reward f32-exact t={t}", eq_nan(r, fx["reward"][t].astype(np.float32)))
-        s = env.get_state()
+        if tl.end()[0]:
+            # an exempt (margin < 1e-9) sample really differed: from here on the device would follow
+            # another trajectory than the reference did.  The fixture holds the reference's full
+            # post-step state: take it over and go on comparing.
+            env.set_state(**{k: fx["state_" + k][t][None] for k in STATE_KEYS})
+            tl.resync()
+        else:
+            s = env.get_state()
+            assert np.array_equal(s["wp_idx"][0].cpu().numpy(), fx["state_wp_idx"][t])
+            for k in ("pos", "vel", "yaw", "pitch", "real_len", "max_dev", "extra_len"):
+                np.testing.assert_allclose(s[k][0].cpu().numpy(), fx["state_" + k][t], rtol=1e-9, atol=1e-9,
+                                           err_msg=f"{k} t={t}")
         m = fx["reset_mask"][t]
         if m.any():
             env.reset_drones(m[None])
             oa, ca = env.observe()
+            tl.begin(fx["margin"][t], count=False)  # (margin[t] covers the re-observation as well)
             tl.check(f"obs_after t={t}", close(oa[0].cpu().numpy(), fx["obs_after"][t]))
             tl.check(f"vo_count_after t={t}", ca[0].cpu().numpy() == fx["vo_count_after"][t])
-        if tl.end()[0]:
-            break
-        assert np.array_equal(s["wp_idx"][0].cpu().numpy(), fx["state_wp_idx"][t])
-        np.testing.assert_allclose(s["pos"][0].cpu().numpy(), fx["state_pos"][t], rtol=1e-9, atol=1e-9)
-        np.testing.assert_allclose(s["extra_len"][0].cpu().numpy(), fx["state_extra_len"][t],
-                                   rtol=1e-9, atol=1e-9)
+            if tl.end()[0]:
+                tl.resync()  # an observation only: the state behind it is the recorded one
         steps_compared += 1
+    assert steps_compared == T
     raised_checked = False
     flags = env.error_flags()
     assert not (flags & 2), "RVO3D_FLAG_DOMAIN_ERROR on a call the reference completed"
@@ -231,6 +266,7 @@ def run_vs_oracle(world, T, nm=10, autoreset=True, f32_actions=False, radius=Non
         tl.check(f"obs f32-exact t={t}", eq_nan(o, ro.astype(np.float32)))
         tl.check(f"reward f32-exact t={t}", eq_nan(r, rr.astype(np.float32)))
         tl.end()
+        resync_from_oracle(env, ref, tl)  # (before the resets below: both sides reset the same drones)
         if not autoreset and rm.any():
             env.reset_drones(rm)
             ref.reset_drones(rm)
@@ -240,17 +276,19 @@ def run_vs_oracle(world, T, nm=10, autoreset=True, f32_actions=False, radius=Non
             tl.check(f"obs_after t={t}", close(oa.cpu().numpy(), roa))
             tl.check(f"cnt_after t={t}", ca.cpu().numpy() == rca)
             tl.end()
+            resync_from_oracle(env, ref, tl)
         stats["steps"] += E * N
         stats["done"] += int(rd.sum()); stats["finish"] += int(rf.sum())
         stats["vo_rows"] += int(rcnt.sum()); stats["resets"] += int(rm.sum())
     s, rs = env.get_state(), ref.get_state()
+    assert not tl.dropped.any()  # every divergence was re-synchronised
     keep = ~tl.dropped
     for k in ("wp_idx", "arrive", "dest"):
         assert np.array_equal(s[k].cpu().numpy()[keep], rs[k][keep]), k
     for k in ("pos", "vel", "yaw", "pitch", "real_len", "max_dev", "extra_len"):
         np.testing.assert_allclose(s[k].cpu().numpy()[keep], rs[k][keep], rtol=1e-9, atol=1e-9, err_msg=k)
     flags = env.error_flags()
-    if not tl.dropped.any():
+    if tl.resyncs == 0:  # (a diverged env may have met - or missed - such an event on its own path)
         assert (flags & 1) == (1 if ref.nan_count else 0)
         assert bool(flags & 2) == (ref.domain_count > 0)
     env.close()
@@ -307,6 +345,7 @@ def test_values_on_file_follow_outside_state_changes():
         s, rs = env.get_state(), ref.get_state()
         assert np.array_equal(s["wp_idx"].cpu().numpy()[keep], rs["wp_idx"][keep]), t
         np.testing.assert_allclose(s["max_dev"].cpu().numpy()[keep], rs["max_dev"][keep], rtol=1e-9, atol=1e-9)
+        resync_from_oracle(env, ref, tl)
     assert switches > 20, switches
     env.close()
     print(tl.finish(waypoint_switches=switches))
@@ -435,6 +474,7 @@ def test_drones_far_outside_the_map_bypass_the_fp32_filters(N, E):
         tl.check(f"obs t={t}", eq_nan(obs.cpu().numpy(), ro.astype(np.float32)))
         tl.check(f"reward t={t}", eq_nan(rew.cpu().numpy(), rr.astype(np.float32)))
         tl.end()
+        resync_from_oracle(env, ref, tl)
         rows += int(rcnt.sum())
     assert rows > 0
     env.close()
@@ -513,7 +553,7 @@ def test_step_policy_trainer_glue():
     rng = np.random.default_rng(3)
     tl = Tally("step_policy_glue", E)
     rows = 0
-    tainted = np.zeros((E, 1), bool)  # envs whose action itself was decided by a last bit
+    ties = 0  # (env, step) pairs whose action itself was decided by a last bit of the velocity
     for t in range(40):
         a_inc = rng.normal(0, 0.6, (E, N, 3)).clip(-1, 1).astype(np.float32)
         vel = ref.get_state()["vel"]
@@ -521,14 +561,15 @@ def test_step_policy_trainer_glue():
         a2 = np.round(a_inc, 2)                      # float32, as in the trainer
         abs_action = np.round(env.acceler * a2 + vel, 2)
         assert a2.dtype == np.float32 and abs_action.dtype == np.float64
-        obs, cnt, rew, done, info, fin = env.step_policy(torch.from_numpy(a_inc).cuda(), autoreset=True)
-        ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(abs_action)
         # The glue's own rounding is a decision too: 0.5 * a + vel can sit on a .5 tie
         # (vel is a decimal when pitch = +-90 deg) where the last bit of vel - libm noise
-        # of sin/cos - decides.  An env whose two runs rounded differently has a
-        # different future and leaves the comparison.
-        tainted |= (np.round(env.acceler * a2 + gvel, 2) != abs_action).any(axis=(1, 2))[:, None]
-        tl.dropped |= tainted[:, 0]
+        # of sin/cos - decides.  An env whose two sides would round differently is brought back
+        # onto the oracle's state first (the last bit of its velocity included), so that both step
+        # with the same action; it is counted, not dropped.
+        tainted = (np.round(env.acceler * a2 + gvel, 2) != abs_action).any(axis=(1, 2))
+        ties += resync_from_oracle(env, ref, tl, extra=tainted)
+        obs, cnt, rew, done, info, fin = env.step_policy(torch.from_numpy(a_inc).cuda(), autoreset=True)
+        ro, rcnt, rr, rd, ri, rf, rm = ref.step_autoreset(abs_action)
         tl.begin(ref.margin())
         tl.check(f"done t={t}", done.cpu().numpy() == rd)
         tl.check(f"finish t={t}", fin.cpu().numpy() == rf)
@@ -536,13 +577,13 @@ def test_step_policy_trainer_glue():
         tl.check(f"obs t={t}", eq_nan(obs.cpu().numpy(), ro.astype(np.float32)))
         tl.check(f"reward t={t}", eq_nan(rew.cpu().numpy(), rr.astype(np.float32)))
         tl.end()
+        resync_from_oracle(env, ref, tl)
         rows += int(rcnt.sum())
-    assert tainted.mean() < 0.2
+    assert ties < 0.01 * 40 * E
     s, rs = env.get_state(), ref.get_state()
-    ok_env = ~tl.dropped
-    np.testing.assert_allclose(s["pos"].cpu().numpy()[ok_env], rs["pos"][ok_env], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(s["pos"].cpu().numpy(), rs["pos"], rtol=1e-9, atol=1e-9)
     assert rows > 0
-    tl.finish(action_rounding_ties=int(tainted.sum()), vo_rows=rows)
+    tl.finish(action_rounding_ties=ties, vo_rows=rows)
     env.close()
 
 
@@ -803,7 +844,12 @@ def test_zz_knife_edge_share_over_all_tests():
     k = sum(r["knife"] for r in allr.values())
     km = sum(r["knife_mismatch"] for r in allr.values())
     dropped = sum(r["dropped_envs"] for r in allr.values())
-    tot = dict(tests=len(allr), samples=n, knife=k, knife_mismatch=km, dropped_envs=dropped,
+    resyncs = sum(r.get("resyncs", 0) for r in allr.values())
+    golden = {k: r for k, r in allr.items() if k.startswith("golden/")}
+    assert all(r["steps_compared"] == r["steps"] for r in golden.values())
+    tot = dict(tests=len(allr), samples=n, knife=k, knife_mismatch=km, dropped_envs=dropped, resyncs=resyncs,
+               golden_scenarios=len(golden), golden_steps=sum(r["steps"] for r in golden.values()),
+               golden_steps_compared=sum(r["steps_compared"] for r in golden.values()),
                knife_share=k / max(n, 1), mismatch_share=km / max(n, 1))
     _record_tally("TOTAL", tot)
     print(tot)

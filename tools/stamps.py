@@ -20,6 +20,13 @@ for t in range(10):
 nb = env.launch_info()["blocks"]
 buf = torch.zeros((nb, 32), dtype=torch.int64, device="cuda")
 _lib.check(_lib.lib().rvo3d_debug_stamps(env._h, C.c_void_p(buf.data_ptr())), "stamps")
+if os.environ.get("STAMPS_COLD"):  # the stamped launch finds nothing of the previous one in the Infinity Cache
+    scratch = torch.zeros(int(os.environ.get("STAMPS_COLD_MB", "1024")) << 20, dtype=torch.uint8, device="cuda")
+    if os.environ["STAMPS_COLD"] == "read":
+        scratch.sum()   # clean lines only
+    else:
+        scratch.add_(1)  # dirty lines: the env step's traffic also has to push them out
+    print("cold:", os.environ["STAMPS_COLD"])
 env.step(acts[10], autoreset=True)
 torch.cuda.synchronize()
 s = buf.cpu().numpy().astype(np.int64)
