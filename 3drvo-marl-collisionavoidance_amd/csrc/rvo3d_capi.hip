@@ -139,48 +139,47 @@ int check(rvo3d_env* h, bool need_world, DeviceGuard& g) {
 
 // The compile-time-N instantiation (NFIX) a handle's shape selects, 0 = the generic kernel of its NW.
 // One place decides it: launch_nw() launches it and rvo3d_kernel_name() reports it.
-int pick_nfix(const Params& P) {
+// Which instantiation a handle's shape runs on: the compile-time ring size NFIX (0 = the generic kernel of
+// its NW) and whether N is smaller than it (padded: ghost lanes).  One place decides; launch_nw() launches
+// it and rvo3d_kernel_name() reports it.
+struct Pick { int nfix; bool pad; };
+Pick pick_kernel(const Params& P) {
   if (P.nw == 1) {
-    if ((P.N == 64 && P.epb == 1) || (P.N == 32 && P.epb == 2) || (P.N == 16 && P.epb == 4)) return P.N;
-    return 0;
+    // a one-wave workgroup of epb envs: segments of 64 / epb lanes
+    const int seg = (P.epb == 1 || P.epb == 2 || P.epb == 4) ? 64 / P.epb : 0;
+    if (seg && P.N == seg) return {seg, false};
+    if (seg >= 32 && P.N < seg) return {seg, true};  // 33..63 drones on the 64 kernel, 22..31 on the 32 one
+    return {0, false};
   }
-  if (!P.env_train) return 0;  // (the evaluator's multi-wave envs run the generic kernels)
-  if (P.nw == 2 && P.N == 128) return 128;
-  if (P.nw == 4 && P.N == 256) return 256;
-  return 0;
+  // multi-wave workgroups: the compile-time kernels take any N up to their size
+  if (P.nw == 2) return {128, true};
+  if (P.nw == 4) return {256, true};
+  return {0, false};
 }
 
-template <int MODE, int NW, int NFIX, bool TRAIN>
+template <int MODE, int NW, int NFIX, bool TRAIN, bool PAD>
 void launch_inst(rvo3d_env* h, const Params& P, hipStream_t s) {
-  hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NFIX, TRAIN>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+  hipLaunchKernelGGL((rvo3d::env_kernel<MODE, NW, NFIX, TRAIN, PAD>), dim3(h->blocks), dim3(h->threads), h->lds, s, P);
+}
+template <int MODE, int NW, int NFIX, bool PAD>
+void launch_train(rvo3d_env* h, const Params& P, hipStream_t s) {
+  // both env_train modes have their instantiations (the evaluator of train/policy_test.py:46 runs env_train = False)
+  if (P.env_train) launch_inst<MODE, NW, NFIX, true, PAD>(h, P, s);
+  else launch_inst<MODE, NW, NFIX, false, PAD>(h, P, s);
 }
 
 template <int MODE, int NW>
 int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
-  const int nfix = pick_nfix(P);
-  if (NW == 1) {
-    // one-wave workgroups: both env_train modes have their compile-time-N instantiations (the
-    // evaluator of train/policy_test.py:46 runs env_train = False at 16 / 32 / 64 drones too)
-    constexpr int W1 = NW == 1 ? 1 : NW;  // (keeps the other NW from instantiating these)
-    if (P.env_train) {
-      if (nfix == 64) launch_inst<MODE, W1, NW == 1 ? 64 : 0, true>(h, P, s);
-      else if (nfix == 32) launch_inst<MODE, W1, NW == 1 ? 32 : 0, true>(h, P, s);
-      else if (nfix == 16) launch_inst<MODE, W1, NW == 1 ? 16 : 0, true>(h, P, s);
-      else launch_inst<MODE, NW, 0, true>(h, P, s);
-    } else {
-      if (nfix == 64) launch_inst<MODE, W1, NW == 1 ? 64 : 0, false>(h, P, s);
-      else if (nfix == 32) launch_inst<MODE, W1, NW == 1 ? 32 : 0, false>(h, P, s);
-      else if (nfix == 16) launch_inst<MODE, W1, NW == 1 ? 16 : 0, false>(h, P, s);
-      else launch_inst<MODE, NW, 0, false>(h, P, s);
-    }
-  } else if (!P.env_train) {
-    launch_inst<MODE, NW, 0, false>(h, P, s);
-  } else if (NW == 2 && nfix == 128) {
-    launch_inst<MODE, NW, NW == 2 ? 128 : 0, true>(h, P, s);
-  } else if (NW == 4 && nfix == 256) {
-    launch_inst<MODE, NW, NW == 4 ? 256 : 0, true>(h, P, s);
+  const Pick k = pick_kernel(P);
+  if constexpr (NW == 1) {
+    if (k.nfix == 64) { if (k.pad) launch_train<MODE, 1, 64, true>(h, P, s); else launch_train<MODE, 1, 64, false>(h, P, s); }
+    else if (k.nfix == 32) { if (k.pad) launch_train<MODE, 1, 32, true>(h, P, s); else launch_train<MODE, 1, 32, false>(h, P, s); }
+    else if (k.nfix == 16) launch_train<MODE, 1, 16, false>(h, P, s);
+    else launch_train<MODE, 1, 0, false>(h, P, s);
+  } else if constexpr (NW == 2 || NW == 4) {
+    launch_train<MODE, NW, 64 * NW, true>(h, P, s);
   } else {
-    launch_inst<MODE, NW, 0, true>(h, P, s);
+    launch_train<MODE, NW, 0, false>(h, P, s);
   }
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
@@ -196,12 +195,13 @@ int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
   }
 }
 
+// (only the generic kernels can need more than 64 KiB: the compile-time ones stop at 256 drones = 40 KiB)
 template <int MODE, int NW>
 hipError_t allow_lds(int bytes) {
-  hipError_t e = hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW>,
+  hipError_t e = hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW, 0, true, false>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW, 0, false>,
+  return hipFuncSetAttribute((const void*)rvo3d::env_kernel<MODE, NW, 0, false, false>,
                              hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 template <int NW>
@@ -311,8 +311,10 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   P.nw = nw <= 1 ? 1 : (nw <= 2 ? 2 : (nw <= 4 ? 4 : 8));
   int epb = P.nw == 1 ? 64 / N : 1;
   if (epb > P.E) epb = P.E;
-  const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)N, 64);
-  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, N, P.nw);
+  // nw = 2 / 4: the compile-time kernels for 128 / 256 drones, any N up to that (ghost lanes)
+  const int ring = (P.nw == 2 || P.nw == 4) ? 64 * P.nw : N;
+  const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)ring, 64);
+  size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, ring, P.nw);
 #ifdef RVO3D_DIAG
   if (const char* pad = std::getenv("RVO3D_LDS_PAD")) lds += (size_t)std::atoi(pad);  // diagnostics build only: cap occupancy
 #endif
@@ -362,9 +364,7 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   h->blocks = (P.E + epb - 1) / epb;
   h->lds = (int)lds;
   if (lds > 64 * 1024) {
-    const bool ok = P.nw == 1 ? allow_lds_all<1>((int)lds)
-                  : P.nw == 2 ? allow_lds_all<2>((int)lds)
-                  : P.nw == 4 ? allow_lds_all<4>((int)lds) : allow_lds_all<8>((int)lds);
+    const bool ok = P.nw == 1 ? allow_lds_all<1>((int)lds) : (P.nw == 8 && allow_lds_all<8>((int)lds));
     if (!ok) {
       return fail(RVO3D_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     }
@@ -606,6 +606,67 @@ int rvo3d_step_autoreset(rvo3d_env* h, const void* actions, int32_t action_dtype
   RVO3D_API_END
 }
 
+int rvo3d_policy_sample(const rvo3d_policy_heads* hd, int64_t rows, float std_factor, uint64_t seed,
+                        uint64_t step, float* act, float* logp, float* val, float* dbg_mu, float* dbg_raw,
+                        void* stream) {
+  RVO3D_API_BEGIN
+  if (!hd || !hd->h_pi || !hd->h_v || !hd->log_std || !act || !logp || !val)
+    return fail(RVO3D_ERR_INVALID, "null pointer");
+  if (rows < 0) return fail(RVO3D_ERR_INVALID, "rows < 0");
+  if (rows == 0) return RVO3D_OK;
+  rvo3d::PolicySampleArgs A;
+  A.h_pi = hd->h_pi; A.h_v = hd->h_v; A.ld_pi = hd->ld_pi; A.ld_v = hd->ld_v;
+  A.hidden = hd->hidden; A.tanh_out = hd->hidden == 0 ? 0 : hd->tanh_out;  // (mu given: already activated)
+  A.w_pi = hd->w_pi; A.b_pi = hd->b_pi; A.w_v = hd->w_v; A.b_v = hd->b_v; A.log_std = hd->log_std;
+  A.std_factor = std_factor; A.seed = seed; A.step = step; A.rows = rows;
+  A.act = act; A.logp = logp; A.val = val; A.dbg_mu = dbg_mu; A.dbg_raw = dbg_raw;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hd->hidden == 0) {
+    if (hd->ld_pi < 3 || hd->ld_v < 1) return fail(RVO3D_ERR_INVALID, "hidden == 0 needs ld_pi >= 3 and ld_v >= 1");
+    hipLaunchKernelGGL(rvo3d::policy_sample_direct_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, A);
+  } else {
+    if (!hd->w_pi || !hd->b_pi || !hd->w_v || !hd->b_v) return fail(RVO3D_ERR_INVALID, "head weights are required");
+    const bool bf = hd->dtype == RVO3D_BF16;
+    if (!bf && hd->dtype != RVO3D_F32) return fail(RVO3D_ERR_INVALID, "dtype must be RVO3D_F32 or RVO3D_BF16");
+    const int per_chunk = bf ? 256 : 128;  // 32 lanes x 16 bytes
+    const int nch = hd->hidden / per_chunk;
+    if (hd->hidden % per_chunk != 0 || (nch != 1 && nch != 2 && nch != 4 && nch != 8) || hd->hidden > 1024)
+      return fail(RVO3D_ERR_INVALID, "hidden must be 128 / 256 / 512 / 1024 (float32) or 256 / 512 / 1024 (bfloat16)");
+    const size_t es = bf ? 2 : 4;
+    if (hd->ld_pi < hd->hidden || hd->ld_v < hd->hidden || (hd->ld_pi * es) % 16 || (hd->ld_v * es) % 16 ||
+        (reinterpret_cast<uintptr_t>(hd->h_pi) & 15) || (reinterpret_cast<uintptr_t>(hd->h_v) & 15))
+      return fail(RVO3D_ERR_INVALID, "hidden activations must be 16-byte aligned rows of at least `hidden` elements");
+    const dim3 grid((unsigned)((rows + 127) / 128)), blk(256);  // 4 waves x 32 rows
+#define RVO3D_PS(T, N) hipLaunchKernelGGL((rvo3d::policy_sample_kernel<T, N>), grid, blk, 0, s, A)
+    if (bf) {
+      if (nch == 1) RVO3D_PS(rvo3d::bf16_t, 1); else if (nch == 2) RVO3D_PS(rvo3d::bf16_t, 2); else RVO3D_PS(rvo3d::bf16_t, 4);
+    } else {
+      if (nch == 1) RVO3D_PS(float, 1); else if (nch == 2) RVO3D_PS(float, 2); else if (nch == 4) RVO3D_PS(float, 4); else RVO3D_PS(float, 8);
+    }
+#undef RVO3D_PS
+  }
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
+int rvo3d_rollout_account(int32_t E, int32_t N, const float* reward, const uint8_t* done, const uint8_t* finish,
+                          int32_t sanitize, int32_t max_ep_len, int32_t epoch_end, float* rew_slot, float* ep_ret,
+                          int32_t* ep_len, uint8_t* cut_slot, uint8_t* extra_mask, double* sums, int32_t* any_extra,
+                          void* stream) {
+  RVO3D_API_BEGIN
+  if (E < 1 || N < 1 || N > rvo3d::kMaxThreads) return fail(RVO3D_ERR_INVALID, "need num_envs >= 1 and 1 <= num_drones <= 512");
+  if (!reward || !done || !finish || !rew_slot || !ep_ret || !ep_len || !cut_slot || !extra_mask || !sums || !any_extra)
+    return fail(RVO3D_ERR_INVALID, "null pointer");
+  rvo3d::AccountArgs A{E, N, reward, done, finish, sanitize, max_ep_len, epoch_end, rew_slot, ep_ret, ep_len,
+                       cut_slot, extra_mask, sums, any_extra};
+  hipLaunchKernelGGL(rvo3d::rollout_account_kernel, dim3((unsigned)E), dim3((unsigned)align_up((size_t)N, 64)), 0,
+                     static_cast<hipStream_t>(stream), A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
 int rvo3d_set_reward_f64(rvo3d_env* h, double* reward64) {
   RVO3D_API_BEGIN
   if (!h) return fail(RVO3D_ERR_INVALID, "null handle");
@@ -747,8 +808,9 @@ int rvo3d_kernel_name(rvo3d_env* h, int32_t mode, char* buf, int32_t cap) {
   RVO3D_API_BEGIN
   if (!h || !buf || cap < 1) return fail(RVO3D_ERR_INVALID, "null handle / buffer");
   if (mode < 0 || mode > 2) return fail(RVO3D_ERR_INVALID, "mode: 0 observe, 1 step, 2 step + auto-reset");
-  std::snprintf(buf, (size_t)cap, "rvo3d::env_kernel<%d, %d, %d, %s>", (int)mode, h->P.nw, pick_nfix(h->P),
-                h->P.env_train ? "true" : "false");
+  const Pick k = pick_kernel(h->P);
+  std::snprintf(buf, (size_t)cap, "rvo3d::env_kernel<%d, %d, %d, %s, %s>", (int)mode, h->P.nw, k.nfix,
+                h->P.env_train ? "true" : "false", k.pad ? "true" : "false");
   return RVO3D_OK;
   RVO3D_API_END
 }

@@ -28,7 +28,8 @@
 //
 // Files: rvo3d_params.hpp (parameter blocks), rvo3d_math.hpp (arithmetic model, per-drone
 // pieces), rvo3d_lds.hpp (LDS views), rvo3d_pairs.hpp (pair pipeline), rvo3d_step.hpp (the step
-// kernel), rvo3d_aux_kernels.hpp (resets, tables, classical RVO selection).
+// kernel), rvo3d_aux_kernels.hpp (resets, tables, classical RVO selection), rvo3d_rollout_kernels.hpp (the
+// trainer's per-step glue: policy heads + sampling, episode bookkeeping).
 #pragma once
 
 #include "rvo3d_params.hpp"
@@ -37,3 +38,4 @@
 #include "rvo3d_pairs.hpp"
 #include "rvo3d_step.hpp"
 #include "rvo3d_aux_kernels.hpp"
+#include "rvo3d_rollout_kernels.hpp"

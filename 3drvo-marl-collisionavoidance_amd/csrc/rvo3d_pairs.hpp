@@ -392,7 +392,8 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     // (the last readers of the request masks - the exact stage of the previous sweep, each lane its
     // own slots - are at least one barrier behind: every caller stages or integrates in between)
     const bool far = L.far[el] != 0;
-    if (active && !far) gate_words_shared<NW, false, false>(P, L, d);
+    // (every lane of the workgroup, ghosts of a padded env included: lane e + 32 s computes word s of drone e)
+    if (!far) gate_words_shared<NW, false, false>(P, L, d);
     __syncthreads();
     if (active) {
       uint32_t valid[NW];
@@ -606,7 +607,7 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
   if (GSHARE) {
     // (the request masks were last read by sweep A's exact stage, before the integrate barriers)
     const bool far = L.far[el] != 0;  // uniform over the workgroup (one env)
-    if (active && !far) {
+    if (!far) {  // (every lane, ghosts included: see sweep_env)
       if (P.uniform_rp) gate_words_shared<NW, true, true>(P, L, d);
       else gate_words_shared<NW, true, false>(P, L, d);
     }

@@ -1,0 +1,277 @@
+// rvo3d_rollout_kernels.hpp -- The trainer's per-step glue around the env step, on the device: the two output heads of
+// the actor-critic + action sampling + log-probability + buffer stores in one pass over the hidden activations
+// (policy_sample_kernel), and the episode bookkeeping behind the env step (rollout_account_kernel).
+// Reference: train/policy/multi_ppo.py:193-281 (the rollout loop), policy_rnn_ac.py:57-69, 197-235 (ac.step, the Gaussian actor).
+// Part of the gfx950 device code (see rvo3d_device.hpp for the overview).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rvo3d {
+
+// ---- Philox4x32-10 (Salmon et al., SC'11), counter = (row, step), key = seed -------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t lo0 = c0 * 0xD2511F53u, hi0 = __umulhi(c0, 0xD2511F53u);
+    const uint32_t lo1 = c2 * 0xCD9E8D57u, hi1 = __umulhi(c2, 0xCD9E8D57u);
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// three standard normals from one Philox block (Box-Muller on (0, 1) uniforms)
+__device__ __forceinline__ void normal3(uint64_t seed, uint64_t step, uint64_t row, float eps[3]) {
+  uint32_t x[4];
+  philox4x32_10((uint32_t)row, (uint32_t)(row >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                (uint32_t)(seed >> 32), x);
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)x[0] + 0.5f) * k, u1 = ((float)x[1] + 0.5f) * k;
+  const float u2 = ((float)x[2] + 0.5f) * k, u3 = ((float)x[3] + 0.5f) * k;
+  // (float)x rounds up to 2^32 for the top 128 values: u = 1 then, log(1) = 0 - still finite
+  const float r0 = __builtin_sqrtf(-2.0f * __logf(u0 < 1.0f ? u0 : 0.99999994f));
+  const float r1 = __builtin_sqrtf(-2.0f * __logf(u2 < 1.0f ? u2 : 0.99999994f));
+  float s0, c0, s1, c1;
+  __sincosf(6.283185307179586f * u1, &s0, &c0);
+  __sincosf(6.283185307179586f * u3, &s1, &c1);
+  eps[0] = r0 * c0; eps[1] = r0 * s0; eps[2] = r1 * c1;
+  (void)s1;
+}
+
+struct PolicySampleArgs {
+  const void* h_pi;      // [rows][ld_pi] hidden activations of the actor (T), or - hidden == 0 - mu [rows][3] float
+  const void* h_v;       // [rows][ld_v]  hidden activations of the critic (T), or - hidden == 0 - v [rows] float
+  int64_t ld_pi, ld_v;   // row strides in elements
+  int32_t hidden;        // H (a multiple of 32 * 16 / sizeof(T), see NCH), or 0: no heads, mu / v given
+  int32_t tanh_out;      // 1: mu = tanh(W h + b)   (output_activation = nn.Tanh, policy_rnn_ac.py:197)
+  const float* w_pi;     // [3][H]  nn.Linear weight of the actor's last layer
+  const float* b_pi;     // [3]
+  const float* w_v;      // [H]
+  const float* b_v;      // [1]
+  const float* log_std;  // [3]     GaussianActor.log_std (policy_rnn_ac.py:198)
+  float std_factor;
+  uint64_t seed, step;
+  int64_t rows;
+  float* act;            // [rows][3]  np.round(a, 2) in float32, what the buffer stores (multi_ppo.py:197) and the env steps from
+  float* logp;           // [rows]     log-probability of the UNROUNDED sample (policy_rnn_ac.py:63-64)
+  float* val;            // [rows]
+  float* dbg_mu;         // optional [rows][3]
+  float* dbg_raw;        // optional [rows][3]: the unrounded sample
+};
+
+__device__ __forceinline__ void finish_row(const PolicySampleArgs& A, int64_t row, float z0, float z1, float z2) {
+  // GaussianActor._distribution (policy_rnn_ac.py:217-222): std = clamp(std_factor * exp(log_std) + 1e-6, 1e-4, 10);
+  // a ~ Normal(mu, std); logp = sum_k log N(a_k; mu_k, std_k)
+  float mu[3] = {z0, z1, z2};
+  if (A.tanh_out) { mu[0] = tanhf(z0); mu[1] = tanhf(z1); mu[2] = tanhf(z2); }
+  float eps[3];
+  normal3(A.seed, A.step, (uint64_t)row, eps);
+  float lp = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float sd = A.std_factor * __expf(A.log_std[k]) + 1e-6f;
+    sd = sd < 1e-4f ? 1e-4f : (sd > 10.0f ? 10.0f : sd);
+    const float a = mu[k] + sd * eps[k];
+    const float d = a - mu[k];
+    lp += -(d * d) / (2.0f * sd * sd) - __logf(sd) - 0.9189385332046727f;
+    A.act[row * 3 + k] = __builtin_rintf(a * 100.0f) / 100.0f;  // np.round(float32, 2): rint(a * 100) / 100
+    if (A.dbg_mu) A.dbg_mu[row * 3 + k] = mu[k];
+    if (A.dbg_raw) A.dbg_raw[row * 3 + k] = a;
+  }
+  A.logp[row] = lp;
+}
+
+// hidden == 0: mu and v come from the caller's own network (e.g. the biGRU actor-critic); one lane per row.
+__global__ void __launch_bounds__(256) policy_sample_direct_kernel(const PolicySampleArgs A) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= A.rows) return;
+  const float* mu = static_cast<const float*>(A.h_pi) + row * A.ld_pi;
+  finish_row(A, row, mu[0], mu[1], mu[2]);
+  A.val[row] = static_cast<const float*>(A.h_v)[row * A.ld_v];
+}
+
+// The two heads ([H] -> 3 and [H] -> 1) as one pass over the hidden activations: HBM-bound (2 H elements read
+// per row, 20 bytes written), no matrix core involved.  A wave takes 32 rows at a time: lanes 0-31 read the
+// actor's hidden row, lanes 32-63 the critic's, 16 B per lane and chunk (one row = NCH chunks of 32 lanes);
+// the head weights sit in registers.  Four rows are reduced together (a butterfly that halves the live values
+// per step: 18 cross-lane moves for four rows of three sums instead of 60), after eight such quads every lane
+// of a half-wave owns one row's sums and finishes it: tanh, sample, log-probability, stores.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPL = 4;
+  __device__ static void unpack(const uint4& v, float x[4]) {
+    x[0] = __builtin_bit_cast(float, v.x); x[1] = __builtin_bit_cast(float, v.y);
+    x[2] = __builtin_bit_cast(float, v.z); x[3] = __builtin_bit_cast(float, v.w);
+  }
+};
+struct bf16_t { uint16_t bits; };
+template <> struct Elem<bf16_t> {
+  static constexpr int EPL = 8;
+  __device__ static void unpack(const uint4& v, float x[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      x[2 * i] = __builtin_bit_cast(float, w[i] << 16);
+      x[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u);
+    }
+  }
+};
+
+template <typename T, int NCH>
+__global__ void __launch_bounds__(256) policy_sample_kernel(const PolicySampleArgs A) {
+  constexpr int EPL = Elem<T>::EPL;
+  const int lane = threadIdx.x & 63, l32 = lane & 31;
+  const bool is_v = lane >= 32;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row0 = wave * 32;
+  if (row0 >= A.rows) return;  // whole waves only: no barrier in this kernel
+  const T* const base = static_cast<const T*>(is_v ? A.h_v : A.h_pi);
+  const int64_t ld = is_v ? A.ld_v : A.ld_pi;
+  // head weights of this lane's elements: actor lanes three rows of w_pi, critic lanes w_v and two zero rows
+  float w0[NCH][EPL], w1[NCH][EPL], w2[NCH][EPL];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      const int e = (c * 32 + l32) * EPL + i;
+      w0[c][i] = is_v ? A.w_v[e] : A.w_pi[e];
+      w1[c][i] = is_v ? 0.f : A.w_pi[A.hidden + e];
+      w2[c][i] = is_v ? 0.f : A.w_pi[2 * A.hidden + e];
+    }
+  float mine0 = 0.f, mine1 = 0.f, mine2 = 0.f;  // the sums of the row this lane ends up owning
+  const int b4 = (l32 >> 4) & 1, b3 = (l32 >> 3) & 1, q_mine = l32 & 7;
+  // raw 16-byte chunks of four rows; the next quad's are requested before the current quad is reduced
+  typedef uint4 raw_t;
+  raw_t cur[4][NCH], nxt[4][NCH];
+  auto request = [&](int q, raw_t dst[4][NCH]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int64_t row = row0 + 4 * q + r;
+      if (row >= A.rows) row = A.rows - 1;  // (a ragged tail re-reads the last row; its results are not stored)
+      const T* src = base + row * ld + (int64_t)l32 * EPL;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) dst[r][c] = *reinterpret_cast<const raw_t*>(src + c * 32 * EPL);
+    }
+  };
+  request(0, cur);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (q + 1 < 8) request(q + 1, nxt);
+    float p[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float x[EPL];
+        Elem<T>::unpack(cur[r][c], x);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) {
+          s0 = __builtin_fmaf(x[i], w0[c][i], s0);
+          s1 = __builtin_fmaf(x[i], w1[c][i], s1);
+          s2 = __builtin_fmaf(x[i], w2[c][i], s2);
+        }
+      }
+      p[r][0] = s0; p[r][1] = s1; p[r][2] = s2;
+    }
+    // butterfly over the 32 lanes of the half-wave.  xor 16: lanes with bit 4 clear keep rows 0, 1 and hand
+    // rows 2, 3 over (and the other way round); xor 8: bit 3 picks one of the two; xor 4, 2, 1: plain sums.
+    float k2[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float keep = b4 ? p[2 + j][k] : p[j][k];
+        const float give = b4 ? p[j][k] : p[2 + j][k];
+        k2[j][k] = keep + __shfl_xor(give, 16, 64);
+      }
+    float k1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float keep = b3 ? k2[1][k] : k2[0][k];
+      const float give = b3 ? k2[0][k] : k2[1][k];
+      k1[k] = keep + __shfl_xor(give, 8, 64);
+    }
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) k1[k] += __shfl_xor(k1[k], m, 64);
+    // every lane with bits (4, 3) = (b4, b3) now holds row 4 q + 2 b4 + b3 of the quad; lane q of them keeps it
+    if (q == q_mine) { mine0 = k1[0]; mine1 = k1[1]; mine2 = k1[2]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) cur[r][c] = nxt[r][c];
+  }
+  const int64_t row = row0 + 4 * q_mine + 2 * b4 + b3;
+  if (row >= A.rows) return;
+  if (is_v) A.val[row] = mine0 + A.b_v[0];
+  else finish_row(A, row, mine0 + A.b_pi[0], mine1 + A.b_pi[1], mine2 + A.b_pi[2]);
+}
+
+// ---- episode bookkeeping of one rollout step (multi_ppo.py:217-281), one thread per drone, one env per workgroup ----
+struct AccountArgs {
+  int32_t E, N;
+  const float* reward;     // [E][N]  the env step's reward (may be inf / nan, survey Q9)
+  const uint8_t* done;     // [E][N]
+  const uint8_t* finish;   // [E][N]
+  int32_t sanitize;        // 1: inf / nan rewards enter the buffer as 0
+  int32_t max_ep_len;      // timeout: ep_len > max_ep_len (multi_ppo.py:266)
+  int32_t epoch_end;       // 1: last step of the epoch - every path ends, every drone is reset (multi_ppo.py:244-264)
+  float* rew_slot;         // [E][N]  buffer slot of this step
+  float* ep_ret;           // [E][N]  running episode return
+  int32_t* ep_len;         // [E][N]
+  uint8_t* cut_slot;       // [E]     finish_path(0) for every drone of the env behind this step
+  uint8_t* extra_mask;     // [E][N]  drones the trainer still has to reset (timeouts, epoch end) - the env step reset done | finish itself
+  double* sums;            // [E][2]  per env: += sum of finished episodes' returns, += their number (one workgroup
+                           //         owns an env's pair: no atomics - 8192 atomic adds per step on two addresses
+                           //         took 100 us; the caller sums over the envs when it reads the statistic)
+  int32_t* any_extra;      // [1]     |= 1 when extra_mask has a non-zero byte
+};
+
+__global__ void __launch_bounds__(512) rollout_account_kernel(const AccountArgs A) {
+  __shared__ int s_term, s_extra;
+  __shared__ double s_sum[8], s_cnt[8];
+  const int e = blockIdx.x, d = threadIdx.x;
+  if (d == 0) { s_term = 0; s_extra = 0; }
+  __syncthreads();
+  double my_sum = 0.0, my_cnt = 0.0;
+  if (d < A.N) {
+    const int64_t g = (int64_t)e * A.N + d;
+    const float r = A.reward[g];
+    const float rf = (r == r && r != __builtin_inff() && r != -__builtin_inff()) ? r : 0.0f;  // nan_to_num(., 0, 0, 0)
+    A.rew_slot[g] = A.sanitize ? rf : r;
+    const float ret = A.ep_ret[g] + rf;
+    const int len = A.ep_len[g] + 1;
+    const bool fin = A.finish[g] != 0, by_step = fin || A.done[g] != 0;
+    const bool timeout = len > A.max_ep_len;
+    const bool ended = by_step || timeout || A.epoch_end;
+    const bool extra = (timeout || A.epoch_end) && !by_step;
+    if (fin || timeout) s_term = 1;   // any drone of the env (multi_ppo.py:229): benign race, same value
+    if (extra) s_extra = 1;
+    A.extra_mask[g] = extra ? 1 : 0;
+    if (ended) { my_sum = (double)ret; my_cnt = 1.0; }
+    A.ep_ret[g] = ended ? 0.0f : ret;
+    A.ep_len[g] = ended ? 0 : len;
+  }
+  // workgroup sums: wave reduction, then one atomic pair per workgroup
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    my_sum += __shfl_xor(my_sum, m, 64);
+    my_cnt += __shfl_xor(my_cnt, m, 64);
+  }
+  if ((d & 63) == 0) { s_sum[d >> 6] = my_sum; s_cnt[d >> 6] = my_cnt; }
+  __syncthreads();
+  if (d == 0) {
+    double ts = 0.0, tc = 0.0;
+    for (int w = 0; w < (int)(blockDim.x + 63) / 64; ++w) { ts += s_sum[w]; tc += s_cnt[w]; }
+    if (tc != 0.0) { A.sums[2 * (size_t)e] += ts; A.sums[2 * (size_t)e + 1] += tc; }
+    if (s_term || A.epoch_end) A.cut_slot[e] = 1;
+    if (s_extra) atomicOr(A.any_extra, 1);
+  }
+}
+
+}  // namespace rvo3d

@@ -195,8 +195,8 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
 // Full workgroups only (the host tabulates the block pattern of a full workgroup, zf_iters > 0:
 // W even, 48 <= W <= 128, rows per workgroup a multiple of 8); the last, partial workgroup of a
 // launch and other widths take the row-pair writer.
-__device__ __forceinline__ bool two_phase_rows(const Params& P, int row0, int nrows) {
-  return P.zf16 && P.cold().zf_iters > 0 && nrows == P.epb * P.N && (row0 & 7) == 0;
+__device__ __forceinline__ bool two_phase_rows(const Params& P, int row0, int nrows, int full_rows) {
+  return P.zf16 && P.cold().zf_iters > 0 && nrows == full_rows && (row0 & 7) == 0;
 }
 
 // part 1: zeros of every 64-B block that holds no proprio byte.  One wave-instruction = 16 blocks
@@ -417,6 +417,10 @@ __device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, 
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
+#ifndef RVO3D_STAGGER_ZEROS
+#define RVO3D_STAGGER_ZEROS 0
+#endif
+
 // 128 VGPRs = 4 waves per SIMD.  One-wave workgroups (N <= 64): the 4096 waves of 64 x 4096 are
 // all resident at once.  N <= 256 (one env per workgroup of 2 or 4 waves): the fourth wave per
 // SIMD is what lets 4 workgroups of 256 drones (40 KB of LDS each) share a CU, and shortens the
@@ -432,10 +436,20 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 // workgroup and the workgroup size are compile-time constants, so the LDS layout and the
 // index arithmetic of the sweeps fold.  NFIX = 0: any N <= 64 * NW.
 // TRAIN = rvo_inter.env_train (rvo_inter.py:14), a compile-time constant of the instantiation.
-template <int MODE, int NW, int NFIX = 0, bool TRAIN = true>
+// PAD: the compile-time kernel takes any N <= NFIX (ghost lanes, see below).  Multi-wave NFIX kernels are always
+// padded; the one-wave ones exist in both flavours (the exact one keeps N a compile-time constant everywhere).
+template <int MODE, int NW, int NFIX = 0, bool TRAIN = true, bool PAD = (NFIX != 0 && NW > 1)>
 __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Params Pin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Params P = Pin;
+  // Inside the kernel P.N is the size of the RING the pair sweeps walk (neighbour d + k mod P.N) and of the
+  // LDS layout; Nr is the number of drones an env really has.  They differ only in the padded compile-time
+  // kernels (PAD): those take any N <= NFIX, the lanes d >= N of an env's segment are ghost drones parked at
+  // infinity - never in range of anybody, never active - so envs of 33..63, 65..127, 129..255 (...) drones run
+  // on the kernels whose index arithmetic folds (no generic-N spills; stage G shared between the lanes
+  // at 128 / 256).
+  static_assert(!PAD || NFIX != 0, "a padded kernel has a compile-time ring size");
+  const int Nr = Pin.N;
   if (NFIX) { P.N = NFIX; P.epb = NFIX <= 64 ? 64 / NFIX : 1; }
   const int tid = threadIdx.x, T = (NW == 1 || NFIX) ? 64 * NW : (int)blockDim.x, N = P.N;
   const Lds L = carve_lds(smem, T, P.nm, P.epb, N, NW);
@@ -443,10 +457,13 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   const int d = tid - el * N;
   const int e0 = blockIdx.x * P.epb;
   const int e = e0 + el;
-  const bool active = (el < P.epb) && (e < P.E);
-  const int g = active ? e * N + d : 0;
+  const bool active = (el < P.epb) && (e < P.E) && (!PAD || d < Nr);
+  const int g = active ? e * (PAD ? Nr : N) + d : 0;
   const int lbase = el * N;
-  const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * N;  // rows of this workgroup
+  const int full_rows = P.epb * (PAD ? Nr : N);                                            // rows of a full workgroup
+  const int nrows = ((P.E - e0) < P.epb ? (P.E - e0) : P.epb) * (PAD ? Nr : N);            // rows of this workgroup
+  const int row0 = e0 * (PAD ? Nr : N);
+  const int lrow = PAD ? el * Nr + d : tid;  // this drone's row among the workgroup's rows (row writers)
   constexpr bool LITE = (MODE == kStepAutoReset);
   // stage G shared between the lanes (gate_words_shared): workgroups of exactly 64 NW drones
   constexpr bool GSH = NW > 1 && NFIX == 64 * NW;
@@ -455,8 +472,36 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // stored as soon as they are final, so that across the sweeps little more than the
   // drone's own 8-value record and its action stay live (registers = waves per SIMD).
   RVO3D_STAMP(0);
+#if RVO3D_STAGGER_ZEROS
+  // (experiment, off: measured slower at 64 x 4096 both cache-warm, 40.1 -> 44.6 us, and cache-cold, 60.9 -> 63.3 us)
+  // Half of the workgroups store their early zero blocks (two-phase row writer: 69 % of the observation
+  // bytes, no data needed) at the very START, the other half where the reset decision is taken.  When a
+  // launch finds nothing in the caches (a rollout: policy GEMMs ran since the last step) all waves of the
+  // one resident round move through the phases together - everybody loads, everybody computes, everybody
+  // stores - and the memory system idles while they compute; with the two halves out of step the stores
+  // of one half fill the load / compute phases of the other.
+  const bool zeros_first = LITE && ((blockIdx.x >> 3) & 1) && two_phase_rows(P, row0, nrows, full_rows);
+  if (zeros_first) early_zero_blocks<NW>(P, L, tid, row0, nrows);
+#else
+  const bool zeros_first = false;
+#endif
   Drone S;
   S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;
+  if (PAD && d >= Nr) {
+    // a ghost: its fp64 record (restaged with everybody's below) sits at +inf - no exact test passes - and its
+    // fp32 record, which stage_f32 never touches again, far outside every gate (1e30^2 overflows to +inf:
+    // the sign test of stage G says "not in range"; never NaN against a real drone)
+    S.x = S.y = S.z = __builtin_inf();
+    const int o = el * 2 * N + d, os = el * N + d;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float v = (k == WX || k == WY || k == WZ) ? 1e30f : (k == WKD ? -1.0f : 0.0f);
+      if (k == WX || k == WY || k == WZ || k == WR) {
+        L.w[k][o] = v;
+        if (d <= (N >> 1)) L.w[k][o + N] = v;
+      } else L.w[k][os] = v;
+    }
+  }
   double a[3] = {0, 0, 0}, cur[3] = {0, 0, 0}, dv[3] = {0, 0, 0};
   double dev = 0, max_dev = 0;
   int wpi = 1;
@@ -538,11 +583,11 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
                                                tmin, collision, gw, false);
     if (active) {
       write_vo_rows(P, L, tid, lbase, g, S, kept);
-      if (P.zf16) stage_row(P, L, tid, g, S, proprio_tail(dv, dev), kept);
+      if (P.zf16) stage_row(P, L, lrow, g, S, proprio_tail(dv, dev), kept);
       else {
         write_proprio(P, g, S, proprio_tail(dv, dev));
         publish_zero_run(P, g, kept);
-        L.kept[tid] = kept;
+        L.kept[lrow] = kept;
       }
       P.max_dev()[g] = max_dev;
       uint32_t dvk_a, dvk_b;
@@ -552,8 +597,8 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       for (int w = 0; w < NW; ++w) P.gcache(w)[g] = gw[w];
     }
     __syncthreads();
-    if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
-    else zero_fill(P, L, tid, e0 * N, nrows);
+    if (P.zf16) row_fill_pairs<NW>(P, L, tid, row0, nrows);
+    else zero_fill(P, L, tid, row0, nrows);
     return;
   }
 
@@ -734,7 +779,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     RVO3D_STAMP(26);
     // (one-wave workgroups: 64 x 4096 -2 %; with several waves per workgroup the blocks go out right
     // before the rows sweep instead, which measured better there)
-    if (NW == 1 && two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
+    if (NW == 1 && !zeros_first && two_phase_rows(P, row0, nrows, full_rows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, row0, nrows);
     RVO3D_STAMP(27);
     if (do_reset) {  // drone.reset (drone.py:270-291); extra_len survives
       S.x = p[0]; S.y = p[1]; S.z = p[2]; S.vx = S.vy = S.vz = 0.0;
@@ -780,7 +825,9 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
     RVO3D_STAMP(6);
     // rows for every env: ir_gym.observation_reward's VO part (the env kept its state) or
     // ir_gym.env_observation with action 0 (the env reset a drone, ir_gym.py:372-383)
-    const bool env_reset = active && (L.any_reset[el] != 0);
+    // (ghost lanes of a padded env follow their env: the shared stage G below needs every lane, and its
+    // barrier every wave)
+    const bool env_reset = (active || (PAD && el < P.epb)) && (L.any_reset[el] != 0);
     bool c2 = false;
     const double aa[3] = {env_reset ? 0.0 : az[0], env_reset ? 0.0 : az[1], env_reset ? 0.0 : az[2]};
     // stage G: the collision sweep delivered the words of the post-move state; only pairs
@@ -798,7 +845,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       have_gw2 = true;
     }
     if (RVO3D_ABLATED(2)) have_gw2 = false;  // diagnostics: the collision sweep was skipped
-    if (NW > 1 && two_phase_rows(P, e0 * N, nrows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, e0 * N, nrows);
+    if (NW > 1 && !zeros_first && two_phase_rows(P, row0, nrows, full_rows) && !RVO3D_ABLATED(16)) early_zero_blocks<NW>(P, L, tid, row0, nrows);
     kept = sweep_env<NW, true, false, TRAIN, GSH>(P, L, tid, el, d, g, active && !RVO3D_ABLATED(4), S, aa,
                                       false, flag, tmin, c2, gw, have_gw2);
   }
@@ -807,7 +854,7 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // stores); then every other byte of the rows - proprio and zeros - in coalesced 16-B stores
   // (a lane writing its own 48 proprio bytes costs as much as the whole zero fill: 64 rows =
   // 64 partial cache lines per store instruction); the state stores drain behind them.
-  const bool two_phase = LITE && two_phase_rows(P, e0 * N, nrows);
+  const bool two_phase = LITE && two_phase_rows(P, row0, nrows, full_rows);
   if (NW > 1 && two_phase) {  // every wave's early zeros have landed before any wave writes kept rows
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -819,17 +866,17 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
       if (two_phase) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       write_vo_rows(P, L, tid, lbase, g, S, kept);
       RVO3D_STAMP(16);
-      if (P.zf16) stage_row(P, L, tid, g, S, ptail, kept);
+      if (P.zf16) stage_row(P, L, lrow, g, S, ptail, kept);
       else { write_proprio(P, g, S, ptail); publish_zero_run(P, g, kept); }
     }
-    if (!P.zf16) L.kept[tid] = kept;
+    if (!P.zf16) L.kept[lrow] = kept;
   }
   __syncthreads();  // the staged rows / L.kept complete
   RVO3D_STAMP(17);
   if (!RVO3D_ABLATED(16)) {
-    if (two_phase) late_row_windows<NW>(P, L, tid, e0 * N, nrows);
-    else if (P.zf16) row_fill_pairs<NW>(P, L, tid, e0 * N, nrows);
-    else zero_fill(P, L, tid, e0 * N, nrows);
+    if (two_phase) late_row_windows<NW>(P, L, tid, row0, nrows);
+    else if (P.zf16) row_fill_pairs<NW>(P, L, tid, row0, nrows);
+    else zero_fill(P, L, tid, row0, nrows);
   }
   RVO3D_STAMP(8);
   if (active) {

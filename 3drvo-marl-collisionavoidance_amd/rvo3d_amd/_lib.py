@@ -66,6 +66,16 @@ class Config(C.Structure):
                 ("map_size", C.c_double * 3)]
 
 
+class PolicyHeads(C.Structure):
+    _fields_ = [("h_pi", C.c_void_p), ("h_v", C.c_void_p), ("ld_pi", C.c_int64), ("ld_v", C.c_int64),
+                ("dtype", C.c_int32), ("hidden", C.c_int32), ("tanh_out", C.c_int32), ("reserved", C.c_int32),
+                ("w_pi", C.c_void_p), ("b_pi", C.c_void_p), ("w_v", C.c_void_p), ("b_v", C.c_void_p),
+                ("log_std", C.c_void_p)]
+
+
+RVO3D_F32, RVO3D_F64, RVO3D_BF16 = 0, 1, 2
+
+
 class StateView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("px", "py", "pz", "vx", "vy", "vz", "yaw", "pitch", "real_len", "max_dev",
@@ -75,7 +85,7 @@ class StateView(C.Structure):
 # every symbol include/rvo3d.h declares (tests check the library exports them all)
 SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
-           "rvo3d_step_policy", "rvo3d_set_reward_f64",
+           "rvo3d_step_policy", "rvo3d_policy_sample", "rvo3d_rollout_account", "rvo3d_set_reward_f64",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
            "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_kernel_name", "rvo3d_version", "rvo3d_last_error")
 
@@ -103,6 +113,8 @@ def lib():
     L.rvo3d_step_autoreset.argtypes = [vp, vp, i32] + [vp] * 8
     L.rvo3d_step_policy.argtypes = [vp, vp, C.c_float] + [vp] * 7 + [i32, vp]
     L.rvo3d_set_reward_f64.argtypes = [vp, vp]
+    L.rvo3d_policy_sample.argtypes = [C.POINTER(PolicyHeads), C.c_int64, C.c_float, C.c_uint64, C.c_uint64] + [vp] * 6
+    L.rvo3d_rollout_account.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 8
     L.rvo3d_des_vel.argtypes = [vp, vp, vp]
     L.rvo3d_rvo_vel.argtypes = [vp, C.POINTER(C.c_double), C.c_double, vp, vp]
     L.rvo3d_state_ptrs.argtypes = [vp, C.POINTER(StateView)]

@@ -154,7 +154,8 @@ class multi_ppo:
                  save_path="test/", save_name="test", load_fname=None, use_gpu=True,
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
-                 dist=None, sanitize_rewards=True, amp=False, reference_order=False, **kwargs):
+                 dist=None, sanitize_rewards=True, amp=False, reference_order=False, fused_rollout=True,
+                 **kwargs):
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
         # The agent order of the reference-order update comes from a generator of its own, seeded like
@@ -163,6 +164,10 @@ class multi_ppo:
         # the process uses np.random.  The action noise, on the other hand, has to differ between the
         # shards: rank r samples from torch's generator seeded seed + r (rank 0 = the reference's seed).
         self._order_rng = np.random.RandomState(seed)
+        self.fused_rollout = bool(fused_rollout)
+        # key of the counter-based action noise of the fused rollout (rvo3d_policy_sample): per rank
+        self._sample_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567 * (
+            dist.get_rank() if (dist is not None and dist.is_initialized()) else 0)) & 0xFFFFFFFFFFFFFFFF
         torch.manual_seed(seed + (dist.get_rank() if (dist is not None and dist.is_initialized()) else 0))
         self.E, self.N = env.E, env.N
         self.robot_num = env.N  # env.ir_gym.drone_num (multi_ppo.py:110)
@@ -203,11 +208,88 @@ class multi_ppo:
         self.log = []
 
     # ---- rollout ------------------------------------------------------------------------
+    def _fused_ok(self):
+        """The fused rollout step (one pass for heads + sampling + stores, one for the bookkeeping) applies
+        to the MLP actor-critic on the GPU; anything else takes the module path of collect()."""
+        if self.device.type != "cuda" or not hasattr(self.ac, "fused_plan") or not self.fused_rollout:
+            return False
+        plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
+        return plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024))
+
+    def _collect_fused(self, final_reset=True):
+        """collect() with the per-step glue on the device: per step ONE cast of the observation (bf16
+        rollouts), the policy GEMMs up to the last hidden layers (mlp_ac.hidden_pair), rvo3d_policy_sample
+        (heads, tanh, sample, log-probability, np.round(a, 2), the three buffer stores), the env step from
+        the stored action, rvo3d_rollout_account (reward slot, episode counters, path cuts, who still
+        needs a reset).  Same semantics as collect(): multi_ppo.py:183-281."""
+        import ctypes as C
+        from .. import _lib
+        env, buf, L = self.env, self.buf, _lib.lib()
+        E, N, T = self.E, self.N, self.steps_per_epoch
+        dt = torch.bfloat16 if self.amp else torch.float32
+        cur_obs, cur_cnt = getattr(self, "_cur", (env.obs, env.vo_count))
+        buf.obs[0].copy_(cur_obs); buf.cnt[0].copy_(cur_cnt)
+        if getattr(self, "_acct", None) is None:
+            self._acct = dict(sums=torch.zeros((E, 2), dtype=torch.float64, device=self.device),
+                              any_extra=torch.zeros(1, dtype=torch.int32, device=self.device),
+                              extra=torch.zeros((E, N), dtype=torch.uint8, device=self.device),
+                              cut=torch.zeros((T, E), dtype=torch.uint8, device=self.device),
+                              step=0)
+        ac = self._acct
+        if ac["cut"].shape[0] != T:
+            ac["cut"] = torch.zeros((T, E), dtype=torch.uint8, device=self.device)
+        ac["sums"].zero_(); ac["cut"].zero_()
+        p = lambda t: C.c_void_p(t.data_ptr())
+        stream = lambda: C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        since_full_reset = 0
+        for t in range(T):
+            plan = self.ac.fused_plan(dt)
+            x = buf.obs[t].view(E * N, env.W)
+            if dt != torch.float32:
+                # ONE kernel: cast + copy into the zero-padded [B, Kp] operand of the first-layer GEMM
+                xp = ac.get("xp")
+                if xp is None or xp.shape != (E * N, plan["k_pad"]) or xp.dtype != dt:
+                    xp = ac["xp"] = torch.zeros((E * N, plan["k_pad"]), dtype=dt, device=self.device)
+                xp[:, :env.W].copy_(x)
+                x = xp
+            with torch.no_grad():
+                hp, hv = self.ac.hidden_pair(x, plan)
+            hd = _lib.PolicyHeads(hp.data_ptr(), hv.data_ptr(), hp.stride(0), hv.stride(0),
+                                  _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32, plan["hidden"],
+                                  1 if plan["tanh"] else 0, 0, plan["w_pi"].data_ptr(), plan["b_pi"].data_ptr(),
+                                  plan["w_v"].data_ptr(), plan["b_v"].data_ptr(), self.ac.log_std.data_ptr())
+            _lib.check(L.rvo3d_policy_sample(C.byref(hd), E * N, 1.0, self._sample_seed, ac["step"],
+                                             p(buf.act[t]), p(buf.logp[t]), p(buf.val[t]), None, None, stream()),
+                       "rvo3d_policy_sample")
+            ac["step"] += 1
+            # the env steps from the stored (rounded) action: rounding twice is rounding once
+            env.step_policy(buf.act[t], autoreset=True, obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
+            since_full_reset += 1
+            epoch_ended = final_reset and t == T - 1
+            ac["any_extra"].zero_()
+            _lib.check(L.rvo3d_rollout_account(E, N, p(env.reward), p(env.done), p(env.finish),
+                                               1 if self.sanitize_rewards else 0, int(self.max_ep_len),
+                                               1 if epoch_ended else 0, p(buf.rew[t]), p(self.ep_ret), p(self.ep_len),
+                                               p(ac["cut"][t]), p(ac["extra"]), p(ac["sums"]), p(ac["any_extra"]),
+                                               stream()), "rvo3d_rollout_account")
+            buf.ptr += 1
+            # only now can an episode have timed out (no episode is longer than the steps since the last
+            # full reset): before that the device is not asked (no synchronisation in the loop)
+            if epoch_ended or (since_full_reset > self.max_ep_len and int(ac["any_extra"].item()) != 0):
+                env.reset_drones(ac["extra"])
+                env.observe(obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
+        buf.cut[:T] |= ac["cut"].bool()
+        self._cur = (buf.obs[T], buf.cnt[T])
+        s = ac["sums"].sum(dim=0).tolist()
+        return float(s[0] / max(s[1], 1.0))
+
     def collect(self, final_reset=True):
         """One epoch of steps_per_epoch env steps (multi_ppo.py:183-281), on the device.  The
         env writes each observation straight into the next buffer slot; the policy GEMMs run
         under ONE autocast region (weight casts are cached across the steps).
         final_reset=False (rollout_profile only) leaves out the epoch-end full reset."""
+        if self._fused_ok():
+            return self._collect_fused(final_reset)
         env, buf = self.env, self.buf
         cur_obs, cur_cnt = getattr(self, "_cur", (env.obs, env.vo_count))
         buf.obs[0].copy_(cur_obs); buf.cnt[0].copy_(cur_cnt)

@@ -37,7 +37,7 @@ enum {
   RVO3D_ERR_STATE = -3     /* call order (e.g. step before load_world) */
 };
 
-enum { RVO3D_F32 = 0, RVO3D_F64 = 1 };
+enum { RVO3D_F32 = 0, RVO3D_F64 = 1, RVO3D_BF16 = 2 };
 
 /* bits of the device error word (rvo3d_error_flags) */
 enum {
@@ -140,6 +140,42 @@ int rvo3d_step_policy(rvo3d_env *h, const float *a_inc, float acceler, float *ob
                       int32_t *vo_count, float *reward, uint8_t *done, uint8_t *info,
                       uint8_t *finish, uint8_t *reset_mask, int32_t autoreset, void *stream);
 
+/* ---- the trainer's per-step glue around the env step (train/policy/multi_ppo.py:193-281), no handle:
+ * plain device pointers, work enqueued on `stream` of the current device ---- */
+
+/* `a, v, logp = ac.step(obs)` (multi_ppo.py:195; policy_rnn_ac.py:57-69, 197-235) from the last hidden
+ * layers on, for `rows` observations at once, plus `a = np.round(a, 2)` (:197) and the stores
+ * `buf.store(.., a, .., v, logp)` (:217-221): the actor's head (hidden -> 3, tanh), the critic's head
+ * (hidden -> 1), a ~ Normal(mu, clamp(std_factor * exp(log_std) + 1e-6, 1e-4, 10)) from a counter-based
+ * generator (Philox4x32-10, counter = (row, step), key = seed: reproducible, no generator state), the
+ * log-probability of the unrounded sample.  hidden > 0: h_pi / h_v are the hidden activations
+ * [rows][ld] of dtype RVO3D_F32 or RVO3D_BF16 (hidden a multiple of 128 resp. 256, at most 1024), the
+ * head weights float32 as nn.Linear stores them (w_pi [3][hidden], b_pi [3], w_v [hidden], b_v [1]).
+ * hidden == 0: h_pi = mu [rows][ld_pi >= 3] and h_v = v [rows][ld_v >= 1], float32, from the caller's own
+ * network (tanh_out ignored).  Outputs: act [rows][3] (rounded: what the buffer stores and
+ * rvo3d_step_policy steps from), logp [rows], val [rows]; dbg_mu / dbg_raw [rows][3] nullable. */
+typedef struct rvo3d_policy_heads {
+  const void *h_pi, *h_v;
+  int64_t ld_pi, ld_v;
+  int32_t dtype, hidden, tanh_out, reserved;
+  const float *w_pi, *b_pi, *w_v, *b_v, *log_std;
+} rvo3d_policy_heads;
+int rvo3d_policy_sample(const rvo3d_policy_heads *heads, int64_t rows, float std_factor, uint64_t seed,
+                        uint64_t step, float *act, float *logp, float *val, float *dbg_mu,
+                        float *dbg_raw, void *stream);
+
+/* The bookkeeping behind `env.drone_step` in the rollout loop (multi_ppo.py:217-281), for E envs x N drones
+ * (N <= 512): the reward into its buffer slot (inf / nan as 0 when sanitize), episode return / length
+ * counters, which paths end behind this step (cut_slot [E]: any drone of the env finished or timed out,
+ * or the epoch ends - finish_path(0) for every drone of the env, :279), which drones the trainer still has
+ * to reset (extra_mask [E][N]: timeouts and, at the epoch's end, everybody the fused step did not reset;
+ * *any_extra |= 1 if there is one), and per env the sum / number of finished episodes' returns
+ * (sums [E][2], doubles, accumulated: the caller zeroes them and adds them up). */
+int rvo3d_rollout_account(int32_t num_envs, int32_t num_drones, const float *reward, const uint8_t *done,
+                          const uint8_t *finish, int32_t sanitize, int32_t max_ep_len, int32_t epoch_end,
+                          float *rew_slot, float *ep_ret, int32_t *ep_len, uint8_t *cut_slot,
+                          uint8_t *extra_mask, double *sums, int32_t *any_extra, void *stream);
+
 /* mdin.drone_step returns its rewards as Python floats (mdin.py:28: rvo_reward + mov_reward in
  * float64).  Attach a device buffer reward64 [E][N] and every following step (all three step
  * entry points) also writes the float64 value next to the float32 one; NULL detaches.  The
@@ -186,7 +222,7 @@ int rvo3d_launch_info(rvo3d_env *h, int32_t *threads, int32_t *envs_per_block,
                       int32_t *blocks, int32_t *lds_bytes);
 
 /* The kernel instantiation this handle's calls launch, as rocprofv3 names it
- * ("rvo3d::env_kernel<MODE, NW, NFIX, TRAIN>"; mode 0 = rvo3d_observe, 1 = rvo3d_step,
+ * ("rvo3d::env_kernel<MODE, NW, NFIX, TRAIN, PAD>"; mode 0 = rvo3d_observe, 1 = rvo3d_step,
  * 2 = rvo3d_step_autoreset / rvo3d_step_policy with autoreset), written to buf (HOST, cap bytes,
  * NUL-terminated): bench.py's roofline.kernel. */
 int rvo3d_kernel_name(rvo3d_env *h, int32_t mode, char *buf, int32_t cap);

@@ -382,6 +382,32 @@ def test_ragged_sizes(N, E, nm):
     assert st["samples"] > 0, st
 
 
+@pytest.mark.parametrize("N,E,kernel", [(48, 9, "<2, 1, 64, true, true>"), (33, 5, "<2, 1, 64, true, true>"),
+                                        (63, 4, "<2, 1, 64, true, true>"), (24, 11, "<2, 1, 32, true, true>"),
+                                        (31, 8, "<2, 1, 32, true, true>"), (65, 4, "<2, 2, 128, true, true>"),
+                                        (96, 6, "<2, 2, 128, true, true>"), (127, 3, "<2, 2, 128, true, true>"),
+                                        (129, 3, "<2, 4, 256, true, true>"), (200, 4, "<2, 4, 256, true, true>"),
+                                        (255, 2, "<2, 4, 256, true, true>")])
+def test_padded_compile_time_kernels(N, E, kernel):
+    """Envs smaller than the compile-time ring of their kernel (round 3): the lanes beyond N are ghost drones
+    parked at infinity.  Dense worlds (many pairs across the ring's seam, resets every few steps), both reset
+    protocols, both env_train modes, per-drone radii; the instantiation is checked by name."""
+    L = 5 + 1.6 * np.sqrt(N)
+    world = synthetic_world(E, N, (L, L, 6.0), n_points=3, nb=3, min_sep=0.6, seed=N)
+    env = BatchedDroneEnv(world)
+    assert env.kernel_name("step_autoreset").endswith(kernel), env.kernel_name("step_autoreset")
+    env.close()
+    for autoreset in (True, False):
+        st = run_vs_oracle(world, T=24, autoreset=autoreset, vlike=not autoreset, seed=3,
+                           name=f"padded/{N}x{E}_ar{int(autoreset)}")
+        assert st["done"] > 0 and (autoreset or st["vo_rows"] > 0), st
+    rng = np.random.default_rng(N)
+    st = run_vs_oracle(world, T=16, autoreset=True, radius=np.round(rng.uniform(0.15, 0.4, (E, N)), 2),
+                       priority=rng.integers(1, 9, (E, N)).astype(np.float64), env_train=False, seed=5,
+                       name=f"padded/{N}x{E}_eval_rp")
+    assert st["samples"] > 0, st
+
+
 def test_dense_small_nm_truncation():
     """Crowded envs with big radii: many VO rows per drone, nm = 2 forces the
     keep-the-most-urgent truncation (rvo_inter.py:50-56)."""

@@ -1,0 +1,216 @@
+"""The trainer's per-step glue on the device (train/policy/multi_ppo.py:193-281):
+rvo3d_policy_sample (the two heads of the actor-critic, tanh, sampling, log-probability, np.round(a, 2)
+and the buffer stores in one pass) and rvo3d_rollout_account (reward slot, episode counters, path
+cuts), each against a plain PyTorch float32 statement of the same lines - these are floating-point
+kernels: tolerance 1e-5 on mu / v, 1e-4 on log-probabilities (fast log / exp), stated per check -
+and the fused rollout loop as a whole: replaying the stored actions through a second env must
+reproduce every stored observation bit for bit."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from rvo3d_amd import BatchedDroneEnv, _lib, synthetic_world
+from rvo3d_amd.policy import mlp_ac, multi_ppo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _sample(hp, hv, wpi, bpi, wv, bv, log_std, rows, hidden, dtype, tanh=True, seed=7, step=0, std_factor=1.0):
+    L = _lib.lib()
+    act = torch.full((rows, 3), 9.0, device=DEV)
+    logp = torch.full((rows,), 9.0, device=DEV)
+    val = torch.full((rows,), 9.0, device=DEV)
+    mu = torch.zeros((rows, 3), device=DEV)
+    raw = torch.zeros((rows, 3), device=DEV)
+    hd = _lib.PolicyHeads(hp.data_ptr(), hv.data_ptr(), hp.stride(0), hv.stride(0), dtype, hidden,
+                          1 if tanh else 0, 0, wpi.data_ptr() if wpi is not None else None,
+                          bpi.data_ptr() if bpi is not None else None, wv.data_ptr() if wv is not None else None,
+                          bv.data_ptr() if bv is not None else None, log_std.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.rvo3d_policy_sample(C.byref(hd), rows, std_factor, seed, step, _p(act), _p(logp), _p(val),
+                                     _p(mu), _p(raw), st), "rvo3d_policy_sample")
+    torch.cuda.synchronize()
+    return act, logp, val, mu, raw
+
+
+@pytest.mark.parametrize("dt,hidden,rows", [(torch.float32, 256, 4096), (torch.bfloat16, 256, 65536),
+                                            (torch.bfloat16, 512, 1000), (torch.float32, 128, 77),
+                                            (torch.bfloat16, 1024, 130), (torch.float32, 1024, 33)])
+def test_policy_sample_matches_torch(dt, hidden, rows):
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    # the hidden activations as views of wider buffers (row stride 2 H), like the merged first-layer GEMM's halves
+    H2 = torch.relu(torch.randn((rows, 2 * hidden), device=DEV, generator=g)).to(dt)
+    hp, hv = H2[:, :hidden], H2[:, hidden:]
+    wpi = torch.randn((3, hidden), device=DEV, generator=g) * 0.08
+    bpi = torch.randn(3, device=DEV, generator=g) * 0.1
+    wv = torch.randn(hidden, device=DEV, generator=g) * 0.08
+    bv = torch.randn(1, device=DEV, generator=g)
+    log_std = torch.tensor([-1.0, -0.5, -1.5], device=DEV)
+    code = _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32
+    act, logp, val, mu, raw = _sample(hp, hv, wpi, bpi, wv, bv, log_std, rows, hidden, code)
+    # float32 statement of policy_rnn_ac.py:197-235 / :242 on the same (already rounded) hidden activations
+    mu_ref = torch.tanh(hp.double() @ wpi.double().t() + bpi.double())
+    v_ref = hv.double() @ wv.double() + bv.double()
+    assert torch.allclose(mu.double(), mu_ref, atol=2e-5, rtol=0), float((mu.double() - mu_ref).abs().max())
+    assert torch.allclose(val.double(), v_ref, atol=5e-5, rtol=1e-5), float((val.double() - v_ref).abs().max())
+    std = torch.clamp(torch.exp(log_std) + 1e-6, 1e-4, 10.0)
+    lp_ref = torch.distributions.Normal(mu, std).log_prob(raw).sum(-1)
+    assert torch.allclose(logp, lp_ref, atol=1e-4, rtol=1e-5), float((logp - lp_ref).abs().max())
+    # np.round(a, 2) of the trainer (multi_ppo.py:197), in numpy's own float32 arithmetic
+    assert np.array_equal(act.cpu().numpy(), np.round(raw.cpu().numpy(), 2))
+    eps = ((raw - mu) / std).cpu().numpy()
+    assert np.isfinite(eps).all()
+    if rows >= 4096:  # the noise is standard normal, independent between the three components
+        n = eps.size
+        assert abs(eps.mean()) < 4 / math.sqrt(n) and abs(eps.var() - 1) < 6 * math.sqrt(2 / n)
+        c = np.corrcoef(eps.T)
+        assert np.abs(c - np.eye(3)).max() < 5 / math.sqrt(rows)
+        assert abs((np.abs(eps) > 1.959964).mean() - 0.05) < 0.004
+    # reproducible: same key and counter, same numbers; another step, other numbers
+    act2, logp2, val2, _, raw2 = _sample(hp, hv, wpi, bpi, wv, bv, log_std, rows, hidden, code)
+    assert torch.equal(raw, raw2) and torch.equal(logp, logp2) and torch.equal(val, val2)
+    _, _, _, _, raw3 = _sample(hp, hv, wpi, bpi, wv, bv, log_std, rows, hidden, code, step=1)
+    assert not torch.equal(raw, raw3)
+    _, _, _, _, raw4 = _sample(hp, hv, wpi, bpi, wv, bv, log_std, rows, hidden, code, seed=8)
+    assert not torch.equal(raw, raw4)
+
+
+def test_policy_sample_direct_mode_and_std_factor():
+    """hidden = 0: mu / v come from the caller's own network (the biGRU actor-critic); std_factor as the
+    evaluator uses it (post_train.py: std_factor 1e-3 -> std clamps at 1e-4 + ...)."""
+    rows = 5000
+    g = torch.Generator(device=DEV).manual_seed(1)
+    mu_in = torch.tanh(torch.randn((rows, 3), device=DEV, generator=g))
+    v_in = torch.randn((rows, 1), device=DEV, generator=g)
+    log_std = torch.tensor([-1.0, -1.0, -1.0], device=DEV)
+    for sf in (1.0, 1e-3):
+        act, logp, val, mu, raw = _sample(mu_in, v_in, None, None, None, None, log_std, rows, 0, _lib.RVO3D_F32,
+                                          std_factor=sf)
+        assert torch.equal(mu, mu_in) and torch.equal(val, v_in[:, 0])
+        std = torch.clamp(sf * torch.exp(log_std) + 1e-6, 1e-4, 10.0)
+        lp_ref = torch.distributions.Normal(mu, std).log_prob(raw).sum(-1)
+        assert torch.allclose(logp, lp_ref, atol=2e-3 if sf < 1 else 1e-4, rtol=1e-5)
+        assert float(((raw - mu) / std).std()) == pytest.approx(1.0, abs=0.03)
+
+
+def test_policy_sample_rejects_bad_arguments():
+    L = _lib.lib()
+    x = torch.zeros((8, 300), device=DEV)
+    ls = torch.zeros(3, device=DEV)
+    hd = _lib.PolicyHeads(x.data_ptr(), x.data_ptr(), 300, 300, _lib.RVO3D_F32, 300, 1, 0, x.data_ptr(),
+                          x.data_ptr(), x.data_ptr(), x.data_ptr(), ls.data_ptr())
+    assert L.rvo3d_policy_sample(C.byref(hd), 8, 1.0, 0, 0, _p(x), _p(x), _p(x), None, None, None) == -1
+    assert b"hidden" in L.rvo3d_last_error()
+    assert L.rvo3d_policy_sample(None, 8, 1.0, 0, 0, _p(x), _p(x), _p(x), None, None, None) == -1
+
+
+def _account_reference(rew, done, fin, ep_ret, ep_len, sanitize, max_ep_len, epoch_end):
+    """multi_ppo.collect()'s bookkeeping (the module path), statement by statement."""
+    rew_fin = torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0)
+    slot = rew_fin if sanitize else rew
+    ep_ret = ep_ret + rew_fin
+    ep_len = ep_len + 1
+    by_step = (done | fin) != 0
+    timeout = ep_len > max_ep_len
+    if epoch_end:
+        ended = torch.ones_like(by_step); terminal = torch.ones(rew.shape[0], dtype=torch.bool, device=rew.device)
+        extra = ~by_step
+    else:
+        ended = by_step | timeout
+        terminal = ((fin != 0) | timeout).any(dim=1)
+        extra = timeout & ~by_step
+    s = float((ep_ret.double() * ended).sum()); n = float(ended.sum())
+    return slot, ep_ret.masked_fill(ended, 0.0), ep_len.masked_fill(ended, 0), terminal, extra, s, n
+
+
+@pytest.mark.parametrize("E,N", [(37, 5), (16, 64), (9, 100), (3, 300)])
+def test_rollout_account_matches_the_module_path(E, N):
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(E * N)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ep_ret = torch.randn((E, N), device=DEV, generator=g)
+    ep_len = torch.randint(0, 12, (E, N), device=DEV, generator=g, dtype=torch.int32)
+    for it, (sanitize, epoch_end) in enumerate([(1, 0), (0, 0), (1, 0), (1, 1)]):
+        rew = torch.randn((E, N), device=DEV, generator=g)
+        rew[torch.rand((E, N), device=DEV, generator=g) < 0.05] = float("inf")
+        rew[torch.rand((E, N), device=DEV, generator=g) < 0.05] = float("nan")
+        rew[torch.rand((E, N), device=DEV, generator=g) < 0.02] = float("-inf")
+        done = (torch.rand((E, N), device=DEV, generator=g) < 0.05).to(torch.uint8)
+        fin = (torch.rand((E, N), device=DEV, generator=g) < 0.01).to(torch.uint8)
+        want = _account_reference(rew, done, fin, ep_ret, ep_len, sanitize, 10, epoch_end)
+        slot = torch.zeros((E, N), device=DEV)
+        cut = torch.zeros(E, dtype=torch.uint8, device=DEV)
+        extra = torch.full((E, N), 7, dtype=torch.uint8, device=DEV)
+        sums = torch.zeros((E, 2), dtype=torch.float64, device=DEV)
+        anyx = torch.zeros(1, dtype=torch.int32, device=DEV)
+        _lib.check(L.rvo3d_rollout_account(E, N, _p(rew), _p(done), _p(fin), sanitize, 10, epoch_end, _p(slot),
+                                           _p(ep_ret), _p(ep_len), _p(cut), _p(extra), _p(sums), _p(anyx), st),
+                   "rvo3d_rollout_account")
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(slot, nan=-7.0), torch.nan_to_num(want[0], nan=-7.0))
+        assert torch.equal(ep_ret, want[1]) and torch.equal(ep_len, want[2])
+        assert torch.equal(cut.bool(), want[3]) and torch.equal(extra.bool(), want[4])
+        assert float(sums[:, 0].sum()) == pytest.approx(want[5], rel=1e-12, abs=1e-9) and float(sums[:, 1].sum()) == want[6]
+        assert bool(anyx.item()) == bool(want[4].any())
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_fused_rollout_is_a_faithful_rollout(amp):
+    """The fused loop (multi_ppo._collect_fused) on 16 drones x 64 envs: (a) a second env stepped with the
+    STORED actions reproduces every stored observation, count and reward bit for bit - the buffer holds
+    what the env really did; (b) the stored values are the critic's, the stored log-probabilities and
+    actions are consistent with the actor's distribution on the stored observations; (c) cuts and
+    episode statistics equal the module path's bookkeeping applied to the same flags."""
+    E, N, T = 64, 16, 24
+    world = synthetic_world(E, N, (20, 20, 8), n_points=3, seed=4)
+    env = BatchedDroneEnv(world)
+    torch.manual_seed(0)
+    ac = mlp_ac(env.W).cuda()
+    tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3)
+    assert tr._fused_ok()
+    env.reset(); env.observe()
+    mean_ret = tr.collect()
+    buf = tr.buf
+    assert buf.ptr == T
+    # (a) replay
+    env2 = BatchedDroneEnv(world)
+    env2.reset(); o, c = env2.observe()
+    assert torch.equal(o, buf.obs[0]) and torch.equal(c, buf.cnt[0])
+    ep_len = torch.zeros((E, N), dtype=torch.int32, device=DEV)
+    ep_ret = torch.zeros((E, N), device=DEV)
+    ret_sum = ret_n = 0.0
+    for t in range(T):
+        o, c, rew, done, info, fin = env2.step_policy(buf.act[t], autoreset=True)
+        want = _account_reference(rew, done, fin, ep_ret, ep_len, 1, 9, t == T - 1)
+        ep_ret, ep_len = want[1], want[2]
+        ret_sum += want[5]; ret_n += want[6]
+        assert torch.equal(torch.nan_to_num(buf.rew[t], nan=-7.0), torch.nan_to_num(want[0], nan=-7.0)), t
+        assert torch.equal(buf.cut[t], want[3]), t
+        if bool(want[4].any()):
+            env2.reset_drones(want[4]); o, c = env2.observe()
+        assert torch.equal(torch.nan_to_num(o, nan=-7.0), torch.nan_to_num(buf.obs[t + 1], nan=-7.0)), t
+        assert torch.equal(c, buf.cnt[t + 1]), t
+    assert mean_ret == pytest.approx(ret_sum / max(ret_n, 1.0), rel=1e-9, abs=1e-9)
+    # (b) the stored numbers against the module's own float32 forward on the stored observations
+    with torch.no_grad():
+        x = buf.obs[:T].reshape(-1, env.W)
+        d, _ = ac.pi(x)
+        v = ac.v(x)
+    tol = 3e-2 if amp else 1e-4  # bf16 GEMMs in the rollout vs the float32 module
+    assert torch.allclose(buf.val.reshape(-1), v, atol=tol, rtol=tol)
+    z = (buf.act.reshape(-1, 3) - d.mean) / d.stddev   # rounded action: + U(-0.005, 0.005) / std
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1) < 0.05
+    lp_of_stored = d.log_prob(buf.act.reshape(-1, 3)).sum(-1)
+    assert float((buf.logp.reshape(-1) - lp_of_stored).abs().mean()) < (0.12 if amp else 0.06)
+    # (c) the update runs on it
+    st = tr.update(buf.get())
+    assert np.isfinite(st["loss_v"])
+    env.close(); env2.close()
