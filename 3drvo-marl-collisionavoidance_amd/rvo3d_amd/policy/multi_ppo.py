@@ -155,7 +155,7 @@ class multi_ppo:
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
                  dist=None, sanitize_rewards=True, amp=False, reference_order=False, fused_rollout=True,
-                 **kwargs):
+                 rollout_chunk=None, tune_gemms=True, **kwargs):
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
         # The agent order of the reference-order update comes from a generator of its own, seeded like
@@ -165,6 +165,11 @@ class multi_ppo:
         # shards: rank r samples from torch's generator seeded seed + r (rank 0 = the reference's seed).
         self._order_rng = np.random.RandomState(seed)
         self.fused_rollout = bool(fused_rollout)
+        self.rollout_chunk = rollout_chunk  # rows per policy pass of the fused rollout (None / 0: all at once)
+        # the rollout's policy GEMMs ([E*N, 128] x [128, 512], [E*N, 256] x [256, 256], bf16) through PyTorch's
+        # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 1 s per shape) and keeps
+        # the fastest - at 64 x 4096 a 256x256x64 stream-K kernel, 70 us, instead of the heuristic's 84 us
+        self.tune_gemms = bool(tune_gemms)
         # key of the counter-based action noise of the fused rollout (rvo3d_policy_sample): per rank
         self._sample_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567 * (
             dist.get_rank() if (dist is not None and dist.is_initialized()) else 0)) & 0xFFFFFFFFFFFFFFFF
@@ -216,6 +221,31 @@ class multi_ppo:
         plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
         return plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024))
 
+    def _tuned_gemms(self):
+        """Context: TunableOp on for the GEMMs issued inside (and back to its previous state after)."""
+        import contextlib
+        if not self.tune_gemms or self.device.type != "cuda":
+            return contextlib.nullcontext()
+
+        @contextlib.contextmanager
+        def ctx():
+            import torch.cuda.tunable as tun
+            was = tun.is_enabled()
+            if not getattr(self, "_tun_set", False):
+                tun.set_max_tuning_duration(1000)
+                if hasattr(tun, "write_file_on_exit"):
+                    tun.write_file_on_exit(False)  # results stay in the process
+                else:  # this PyTorch writes its results at exit: into the temp dir, not the cwd
+                    import tempfile
+                    tun.set_filename(os.path.join(tempfile.gettempdir(), f"rvo3d_tunableop_{os.getpid()}.csv"))
+                self._tun_set = True
+            tun.enable(True)
+            try:
+                yield
+            finally:
+                tun.enable(was)
+        return ctx()
+
     def _collect_fused(self, final_reset=True):
         """collect() with the per-step glue on the device: per step ONE cast of the observation (bf16
         rollouts), the policy GEMMs up to the last hidden layers (mlp_ac.hidden_pair), rvo3d_policy_sample
@@ -245,23 +275,35 @@ class multi_ppo:
         for t in range(T):
             plan = self.ac.fused_plan(dt)
             x = buf.obs[t].view(E * N, env.W)
-            if dt != torch.float32:
-                # ONE kernel: cast + copy into the zero-padded [B, Kp] operand of the first-layer GEMM
-                xp = ac.get("xp")
-                if xp is None or xp.shape != (E * N, plan["k_pad"]) or xp.dtype != dt:
-                    xp = ac["xp"] = torch.zeros((E * N, plan["k_pad"]), dtype=dt, device=self.device)
-                xp[:, :env.W].copy_(x)
-                x = xp
-            with torch.no_grad():
-                hp, hv = self.ac.hidden_pair(x, plan)
-            hd = _lib.PolicyHeads(hp.data_ptr(), hv.data_ptr(), hp.stride(0), hv.stride(0),
-                                  _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32, plan["hidden"],
-                                  1 if plan["tanh"] else 0, 0, plan["w_pi"].data_ptr(), plan["b_pi"].data_ptr(),
-                                  plan["w_v"].data_ptr(), plan["b_v"].data_ptr(), self.ac.log_std.data_ptr())
-            _lib.check(L.rvo3d_policy_sample(C.byref(hd), E * N, 1.0, self._sample_seed, ac["step"],
-                                             p(buf.act[t]), p(buf.logp[t]), p(buf.val[t]), None, None, stream()),
-                       "rvo3d_policy_sample")
-            ac["step"] += 1
+            act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
+            # (rollout_chunk: the policy can run over the rows in chunks whose activations stay in the 256 MiB
+            # Infinity Cache.  Measured at 64 x 4096, bf16: no gain - 422 / 420 / 427 / 555 us per step for all /
+            # 131072 / 65536 / 32768 rows per pass; the [rows, 256] x [256, 256] GEMMs take 20 us per 65536 rows
+            # either way: they are not bound by HBM.  Off by default.)
+            B = E * N
+            Cn = B if not self.rollout_chunk else min(B, int(self.rollout_chunk))
+            for r0 in range(0, B, Cn):
+                n = min(Cn, B - r0)
+                xc = x[r0:r0 + n]
+                if dt != torch.float32:
+                    # ONE kernel: cast + copy into the zero-padded [rows, Kp] operand of the first-layer GEMM
+                    xp = ac.get("xp")
+                    if xp is None or xp.shape != (Cn, plan["k_pad"]) or xp.dtype != dt:
+                        xp = ac["xp"] = torch.zeros((Cn, plan["k_pad"]), dtype=dt, device=self.device)
+                    xp[:n, :env.W].copy_(xc)
+                    xc = xp[:n]
+                with torch.no_grad(), self._tuned_gemms():
+                    hp, hv = self.ac.hidden_pair(xc, plan)
+                hd = _lib.PolicyHeads(hp.data_ptr(), hv.data_ptr(), hp.stride(0), hv.stride(0),
+                                      _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32, plan["hidden"],
+                                      1 if plan["tanh"] else 0, 0, plan["w_pi"].data_ptr(), plan["b_pi"].data_ptr(),
+                                      plan["w_v"].data_ptr(), plan["b_v"].data_ptr(), self.ac.log_std.data_ptr())
+                # (the generator's counter is (row of the chunk, call number): every call draws fresh noise)
+                _lib.check(L.rvo3d_policy_sample(C.byref(hd), n, 1.0, self._sample_seed, ac["step"],
+                                                 p(act_t[r0:]), p(logp_t[r0:]), p(val_t[r0:]), None, None, stream()),
+                           "rvo3d_policy_sample")
+                ac["step"] += 1
+                del hp, hv
             # the env steps from the stored (rounded) action: rounding twice is rounding once
             env.step_policy(buf.act[t], autoreset=True, obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
             since_full_reset += 1
