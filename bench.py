@@ -187,6 +187,10 @@ def parse_args(argv=None):
     ap.add_argument("--cold-mode", default="rw", choices=["rw", "read"],
                     help="rw: the scratch is read and rewritten (the cache is left full of dirty lines, as after "
                          "the policy GEMMs of a rollout); read: only read (clean lines)")
+    ap.add_argument("--cold-all", action="store_true",
+                    help="profiling only: the scratch is streamed before EVERY launch (warm-up and timed loop included), "
+                         "so that a rocprofv3 trace of the run shows cache-cold launches only; `value` then includes the "
+                         "flush and is not the metric")
     ap.add_argument("--no-rollout", action="store_true",
                     help="skip the `rollout` block (BASELINE config 3 as written: policy forward -> env step -> "
                          "buffer stores, GAE, one PPO update), which runs after the headline timed region")
@@ -357,7 +361,14 @@ def run_rank(args):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
 
+    flush = None
+    if args.cold_all:
+        flush_buf = torch.zeros(max(args.cold_mb, 1) << 20, dtype=torch.uint8, device=dev)
+        flush = (lambda: flush_buf.add_(1)) if args.cold_mode == "rw" else (lambda: flush_buf.sum())
+
     def one_step(t):
+        if flush is not None:
+            flush()
         env.step(acts[t % n_act], autoreset=autoreset)
         if bucket is not None:
             if side is not None:
@@ -394,6 +405,10 @@ def run_rank(args):
     stream = torch.cuda.current_stream(dev)
 
     def timed_launches(between=None):
+        for t in range(5):  # (untimed: the first launches behind a synchronisation carry its wake-up)
+            if between is not None:
+                between()
+            env.step(acts[t % n_act], autoreset=autoreset)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         for t, (a, b) in enumerate(evs):
             if between is not None:
@@ -402,16 +417,17 @@ def run_rank(args):
             env.step(acts[(W + t) % n_act], autoreset=autoreset)
             b.record(stream)
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        ts = np.asarray([a.elapsed_time(b) for a, b in evs])
+        return float(ts.mean()), float(np.median(ts)), float(ts.max())
 
-    kern_ms = timed_launches()
+    kern_ms, kern_med_ms, kern_max_ms = timed_launches(flush)
     # cache-cold: back-to-back launches find the ~54 MB of state the previous launch wrote still in the
     # 256 MiB Infinity Cache; a trainer runs policy GEMMs over several hundred MB between two env steps.
     # Here a scratch buffer of --cold-mb MiB is read and rewritten between two timed launches.
     kern_cold_ms = None
     if not args.no_cold:
         scratch = torch.zeros(max(args.cold_mb, 1) << 20, dtype=torch.uint8, device=dev)
-        kern_cold_ms = timed_launches((lambda: scratch.add_(1)) if args.cold_mode == "rw" else (lambda: scratch.sum()))
+        kern_cold_ms = timed_launches((lambda: scratch.add_(1)) if args.cold_mode == "rw" else (lambda: scratch.sum()))[0]
         del scratch
     flags = env.error_flags()
     coll = None
@@ -471,6 +487,7 @@ def run_rank(args):
                                    f"{'+auto-reset' if autoreset else ''}, f32 actions in HBM",
                        "envs_per_gpu": E, "drones": N, "launch": env.launch_info(),
                        "untimed_steps_before_warmup": args.prewarm, "diag_build": diag,
+                       "cold_all": bool(args.cold_all),
                        "ablate": int(os.environ.get("RVO3D_ABLATE", "0")) if diag else 0,
                        "device_error_word": flags},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -481,7 +498,8 @@ def run_rank(args):
                          "fp64_valu_peak_tflops": 78.6,
                          # the instantiation the library launches for this handle (rvo3d_kernel_name)
                          "kernel": env.kernel_name("step_autoreset" if autoreset else "step"),
-                         "kernel_ms": round(kern_ms, 4),
+                         "kernel_ms": round(kern_ms, 4),  # mean over the K event pairs (what `achieved` uses)
+                         "kernel_ms_median": round(kern_med_ms, 4), "kernel_ms_max": round(kern_max_ms, 4),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "bytes_per_drone_step": B},
         }

@@ -18,8 +18,11 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    # the GPU parity tests append their knife-edge tallies to this file; start each session clean
+    # the GPU parity tests append their knife-edge tallies to this file; a session that runs them starts
+    # clean (a CPU-only session - `-m "not gpu"` - leaves the last GPU run's record alone)
     f = os.path.join(ROOT, "gpurun_out", "parity_tally.json")
+    if "not gpu" in (session.config.getoption("-m") or ""):
+        return
     if os.path.exists(f):
         try:
             os.remove(f)
@@ -33,6 +36,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     the TOTAL line test_zz_knife_edge_share_over_all_tests computed over every test's record."""
     import json
     f = os.path.join(ROOT, "gpurun_out", "parity_tally.json")
+    if "not gpu" in (config.getoption("-m") or ""):
+        return
     try:
         with open(f) as fh:
             tot = json.load(fh).get("TOTAL")

@@ -53,7 +53,11 @@ template <class F> float timeit(F f, int reps) {
   hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
 }
-int main() {
+int main(int argc, char** argv) {
+  // `hbm_rate warm`: every launch touches the SAME 256 MB slot, so the lines are resident in the 256 MiB Infinity
+  // Cache (the regime of back-to-back env steps); default: rotate through 8 slots (nothing is resident)
+  const int nslots = (argc > 1 && argv[1][0] == 'w') ? 1 : 8;
+  printf("%s\n", nslots == 1 ? "WARM: one slot, Infinity-Cache resident" : "COLD: rotating through 2 GB");
   const size_t MB = 1000000, bytesW = 141 * MB, bytesR = 62 * MB;
   // rotate through 8 slots of 256 MB per buffer (2 GB each): every launch touches memory that
   // left the Infinity Cache (256 MiB) long ago.  Largest access per launch: 141 MB < slot.
@@ -64,7 +68,7 @@ int main() {
   }
   hipMemset(A, 0, total); hipMemset(B, 0, total);
   int slot = 0;
-  auto next = [&](size_t) { slot = (slot + 1) % 8; return (size_t)slot * (slot_bytes / 16); };
+  auto next = [&](size_t) { slot = (slot + 1) % nslots; return (size_t)slot * (slot_bytes / 16); };
   for (int geom = 0; geom < 2; ++geom) {
     dim3 g = geom ? dim3(4096) : dim3(2048), t = geom ? dim3(64) : dim3(1024);
     float w = timeit([&] { size_t o = next(0); hipLaunchKernelGGL(k_write, g, t, 0, 0, B + o, bytesW / 16); }, 50);
