@@ -569,6 +569,10 @@ static void env_observe(orc_env *h, int e, work *w, double *obs, int32_t *vo_cou
   for (int i = 0; i < N; ++i) {
     int cnt, vf, col; double tmin;
     tl_margin = h->margin + (e * N + i); tl_site = h->msite + (e * N + i);
+    /* as in env_step's sweep A: a velocity that is the noise a cancelled speed left behind (1e-17 * direction
+     * here, exactly 0 there) decides the sign of v . rel in this observation too - e.g. the re-observation
+     * after OTHER drones of the env were reset (found by tools/fuzz_shapes.py seeds 42 / 43, round 3) */
+    if (h->vnoise[e * N + i]) mg0(0.0);
     config_vo_inf(h, w->st, i, zero, w->scratch, w->rows, &cnt, &vf, &tmin, &col);
     write_obs(h, &w->st[i], w->rows, cnt, obs + (size_t)(e * N + i) * W);
     vo_count[e * N + i] = cnt;

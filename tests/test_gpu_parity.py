@@ -85,7 +85,8 @@ class Tally:
         live = ~self.dropped[:, None]
         firm = (self.mg >= KNIFE) & live
         assert ok[firm].all(), (f"{self.name} {what}: {int((~ok & firm).sum())} firm mismatches at "
-                                f"{np.argwhere(~ok & firm)[:4].tolist()}")
+                                f"{np.argwhere(~ok & firm)[:4].tolist()} (margins {self.mg[~ok & firm][:4].tolist()}, "
+                                f"resyncs so far {self.resyncs})")
         self.bad |= ~ok & ~firm & live
 
     def end(self):

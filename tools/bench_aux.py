@@ -29,7 +29,8 @@ def timed(name, fn, bytes_per_drone=None):
     for i, (a, b) in enumerate(ev):
         a.record(); fn(i); b.record()
     torch.cuda.synchronize()
-    us = float(np.mean([a.elapsed_time(b) for a, b in ev])) * 1e3
+    ts = np.asarray([a.elapsed_time(b) for a, b in ev])
+    us = float(ts[ts <= 3 * np.median(ts)].mean()) * 1e3  # (without host-stall samples, see bench.py)
     extra = "" if bytes_per_drone is None else "  %.0f GB/s of its %d algorithmic bytes per drone" % (E * N * bytes_per_drone / us / 1e3, bytes_per_drone)
     print("%-44s %8.1f us  %.3e drones/s%s" % (name, us, E * N / (us * 1e-6), extra), flush=True)
 

@@ -41,6 +41,9 @@ for c in range(cases):
         kw["f32_actions"] = False
     w = synthetic_world(E, N, (L, L, float(rng.choice([5.0, 8.0, 10.0]))), nb=nb, seed=int(rng.integers(1 << 30)),
                         min_sep=max(0.6, 2.2 * radius + 0.1), n_points=int(rng.integers(2, 5)))
+    if os.environ.get("FUZZ_ONLY") and int(os.environ["FUZZ_ONLY"]) != c:
+        rng.integers(8, 25); rng.integers(1 << 30)  # (the draws of the skipped run)
+        continue
     t0 = time.time()
     st = T.run_vs_oracle(w, T=int(rng.integers(8, 25)), seed=int(rng.integers(1 << 30)), name=f"fuzz/{seed}/{c}", **kw)
     print(f"case {c}: N={N} E={E} map={L} nb={nb} {kw} -> steps {st['steps']} done {st['done']} vo_rows {st['vo_rows']} "
