@@ -222,8 +222,13 @@ __device__ __forceinline__ void early_zero_blocks(const Params& P, const Lds& L,
   for (int i = 0; i < iters; i += 4, p += 4 * step, m >>= 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if ((m >> u) & 1u)
+      if ((m >> u) & 1u) {
+#if RVO3D_ZERO_NT
         __builtin_nontemporal_store((v4f){0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(p + u * step));
+#else
+        *reinterpret_cast<v4f*>(p + u * step) = (v4f){0.f, 0.f, 0.f, 0.f};
+#endif
+      }
   }
 }
 
@@ -417,6 +422,9 @@ __device__ __forceinline__ double mov_reward_k(const Params& P, bool collision, 
 
 enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 
+#ifndef RVO3D_ZERO_NT
+#define RVO3D_ZERO_NT 1  // streaming (non-temporal) stores for the early zero blocks
+#endif
 #ifndef RVO3D_STAGGER_ZEROS
 #define RVO3D_STAGGER_ZEROS 0
 #endif
