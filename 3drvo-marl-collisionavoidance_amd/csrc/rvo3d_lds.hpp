@@ -16,7 +16,7 @@ struct Lds {
   // fp32 image, each env's N slots stored twice ([el][2N]) so that neighbour
   // d + k (mod N) is slot d + k; and the exact-stage request masks
   float* w[12];                                  // x y z r [FL] (stored twice); vx vy vz kd ax ay az prio [FS]
-  unsigned long long* mask2;                     // [T][NW] bit j: run pair_eval(me, j)
+  unsigned long long* mask2;                     // [NW][T] (word-major, see mi()) bit j: run pair_eval(me, j)
   int T;
 };
 

@@ -140,6 +140,14 @@ __device__ __forceinline__ int insert_row(const Params& P, const Lds& L, int g, 
   return kept;
 }
 
+// Request-mask word w of the drone in slot `slot` (slot = its thread index).  Word-major, [NW][T]: the lanes of a
+// wave touch consecutive 8-byte words - conflict-free - where a drone-major [T][NW] layout put them 8 NW bytes
+// apart (NW = 4: four-way bank conflicts on every clear / hand-over / read of the masks).
+template <int NW>
+__device__ __forceinline__ int mi(const Lds& L, int slot, int w) {
+  return NW == 1 ? slot : w * L.T + slot;
+}
+
 // ===== the pair pipeline: whole envs per workgroup, fp32 filters, exact stage on request =====
 enum { WX = 0, WY, WZ, WVX, WVY, WVZ, WR, WKD, WAX, WAY, WAZ, WPRIO };
 
@@ -313,7 +321,7 @@ __device__ __forceinline__ void gate_words_shared(const Params& P, const Lds& L,
   }
 #pragma unroll
   for (int s = 0; s < NW; ++s)
-    L.mask2[own[s] * NW + s] =
+    L.mask2[mi<NW>(L, own[s], s)] =
         (unsigned long long)mr[s] | ((unsigned long long)(TOUCH ? (mt[s] & mr[s]) : 0u) << 32);
 }
 
@@ -400,12 +408,12 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
       valid_offsets<NW>(P.N, d, valid);
 #pragma unroll
       for (int w = 0; w < NW; ++w)
-        gw[w] = far ? valid[w] : ((uint32_t)L.mask2[lane * NW + w] & valid[w]);
+        gw[w] = far ? valid[w] : ((uint32_t)L.mask2[mi<NW>(L, lane, w)] & valid[w]);
     }
     have_gw = true;
   }
 #pragma unroll
-  for (int w = 0; w < NW; ++w) L.mask2[lane * NW + w] = 0ull;
+  for (int w = 0; w < NW; ++w) L.mask2[mi<NW>(L, lane, w)] = 0ull;
   __syncthreads();
   unsigned long long m2r = 0ull;  // NW == 1: my own requests stay in a register
   if (active) {
@@ -546,11 +554,11 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
         if (NW == 1) {
           m2r |= ((unsigned long long)pi0 << jd0) | ((unsigned long long)pi1 << jd1);
         } else {
-          if (pi0) atomicOr(&L.mask2[lane * NW + (jd0 >> 6)], 1ull << (jd0 & 63));
-          if (pi1) atomicOr(&L.mask2[lane * NW + (jd1 >> 6)], 1ull << (jd1 & 63));
+          if (pi0) atomicOr(&L.mask2[mi<NW>(L, lane, jd0 >> 6)], 1ull << (jd0 & 63));
+          if (pi1) atomicOr(&L.mask2[mi<NW>(L, lane, jd1 >> 6)], 1ull << (jd1 & 63));
         }
-        if (pj0) atomicOr(&L.mask2[(el * N + jd0) * NW + (d >> 6)], 1ull << (d & 63));
-        if (pj1) atomicOr(&L.mask2[(el * N + jd1) * NW + (d >> 6)], 1ull << (d & 63));
+        if (pj0) atomicOr(&L.mask2[mi<NW>(L, el * N + jd0, d >> 6)], 1ull << (d & 63));
+        if (pj1) atomicOr(&L.mask2[mi<NW>(L, el * N + jd1, d >> 6)], 1ull << (d & 63));
       }
       // The words filed for the next step's sweep A (same state, another action) keep only the
       // pairs in which somebody is possibly approaching: "approaching" does not depend on the
@@ -565,7 +573,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
 #ifdef RVO3D_DIAG
   if (P.dbg && active && RVO3D_ABLATED(128)) {  // diagnostics build, bit 128 = count: X2 requests of this workgroup (sum, max per lane)
     int c = 0;
-    for (int w = 0; w < NW; ++w) c += __builtin_popcountll(L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull));
+    for (int w = 0; w < NW; ++w) c += __builtin_popcountll(L.mask2[mi<NW>(L, lane, w)] | (w == 0 ? m2r : 0ull));
     atomicAdd(&P.dbg[(size_t)blockIdx.x * 32 + (ROWS ? 22 : 20)], (unsigned long long)c);
     atomicMax(&P.dbg[(size_t)blockIdx.x * 32 + (ROWS ? 23 : 21)], (unsigned long long)c);
   }
@@ -574,7 +582,7 @@ __device__ __forceinline__ int sweep_env(const Params& P, const Lds& L, int lane
     const int lbase = el * N;
 #pragma unroll  // (a rolled loop over the words is smaller but 4 % slower at 128 and 256 drones)
     for (int w = 0; w < NW; ++w) {
-      unsigned long long m2 = L.mask2[lane * NW + w] | (w == 0 ? m2r : 0ull);
+      unsigned long long m2 = L.mask2[mi<NW>(L, lane, w)] | (w == 0 ? m2r : 0ull);
       while (m2) {  // stage X2: exact, requested pairs only
         const int j = 64 * w + __builtin_ctzll(m2);
         m2 &= m2 - 1;
@@ -614,13 +622,13 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const unsigned long long v = L.mask2[lane * NW + w];
+      const unsigned long long v = L.mask2[mi<NW>(L, lane, w)];
       gw[w] = (uint32_t)v;
       touchw[w] = (uint32_t)(v >> 32);
-      if (w) L.mask2[lane * NW + w] = 0ull;
+      if (w) L.mask2[mi<NW>(L, lane, w)] = 0ull;
     }
   }
-  L.mask2[lane * NW] = 0ull;
+  L.mask2[mi<NW>(L, lane, 0)] = 0ull;
   __syncthreads();
   bool coll = false;
   if (active) {
@@ -675,12 +683,12 @@ __device__ __forceinline__ bool collide_env(const Params& P, const Lds& L, int l
           }
         }
         if (ci) coll = true;
-        if (cj) atomicOr(&L.mask2[k * NW], 1ull);
+        if (cj) atomicOr(&L.mask2[mi<NW>(L, k, 0)], 1ull);
       }
     }
   }
   __syncthreads();
-  if (active && (L.mask2[lane * NW] & 1ull)) coll = true;
+  if (active && (L.mask2[mi<NW>(L, lane, 0)] & 1ull)) coll = true;
   return coll;
 }
 
