@@ -482,9 +482,18 @@ class multi_ppo:
         flat = self._bucket()
         if kl is not None:
             flat[-1] = float(kl)
-        d.all_reduce(flat)
-        flat /= d.get_world_size()
+        self._allreduce_bucket()
         return float(flat[-1]) if kl is not None else None
+
+    def _allreduce_bucket(self):
+        """The collective itself: the bucket averaged over the ranks, in place - ONE call on RCCL
+        (ReduceOp.AVG); gloo has no AVG: sum, then divide."""
+        d, flat = self.dist, self._bucket()
+        if d.get_backend() == "nccl":
+            d.all_reduce(flat, op=d.ReduceOp.AVG)
+        else:
+            d.all_reduce(flat)
+            flat /= d.get_world_size()
 
     def _mean_over_ranks(self, x: float) -> float:
         d = self.dist

@@ -15,11 +15,12 @@ Envs are independent, so N GPUs = N shards of 4096 envs each (weak scaling) and 
 step itself needs no data-path collective.  The one collective of the north-star
 design - the RCCL all-reduce of the flattened policy-gradient bucket, the KL estimate
 in its last slot, once per optimizer step (rvo3d_amd.policy.multi_ppo._allreduce_grads /
-update) - is put INSIDE every timed step whenever N > 1 (or with
+update) - is put INSIDE the timed region whenever N > 1 (or with
 --grad-allreduce): the trainer's own code path on the gradients of the MLP(256,256)
-policy of BASELINE config 3 (0.74 MB fp32).  That is the worst case - one optimizer
-step per env step; training does one per several hundred - so the multi-GPU record
-contains real xGMI traffic and the scaling efficiency read from it is a lower bound.
+policy of BASELINE config 3 (0.74 MB fp32).  One collective per --allreduce-every env
+steps (default 3: the training ratio with the reference's defaults - 300 env steps per epoch, then 50 + 50
+optimizer steps; 1 = one per env step, the worst case), so the multi-GPU record contains real xGMI traffic
+at the rate training produces it.
 The collective is issued on a second HIP stream (it depends on nothing the env step
 produces), so it overlaps the next env step the way it would overlap a backward pass;
 --serial-collective puts it on the step's stream instead.
@@ -131,20 +132,18 @@ class GradBucket:
         for p in self.ac.parameters():
             p.grad = torch.ones_like(p)
         self.kl32 = torch.zeros(1, dtype=torch.float32, device=env.device)
+        self.tr._bucket()[-1:].copy_(self.kl32)  # the KL slot (its value does not matter to the cost)
         self.ones = torch.ones(1, dtype=torch.float64, device=env.device)
         self.nbytes = (sum(p.numel() for p in self.ac.parameters()) + 1) * 4
 
     def step(self):
-        # ONE collective: the flattened bucket (sum, then / world) with the KL estimate in its last
-        # slot, exactly as multi_ppo's policy pass issues it (the mean KL is left on the device here:
-        # the trainer's host read of it is not part of the collective's cost)
-        d = self.dist
-        if d is None:
+        # ONE collective: the flattened bucket averaged over the ranks, the KL estimate in its last slot, as
+        # multi_ppo's policy pass issues it (multi_ppo._allreduce_grads; the mean KL is left on the device here:
+        # the trainer's host read of it is not part of the collective's cost).  ONE call per step on RCCL
+        # (ReduceOp.AVG); three launches from Python per step made the loop host-bound at one rank.
+        if self.dist is None:
             return
-        flat = self.tr._bucket()
-        flat[-1:].copy_(self.kl32)
-        d.all_reduce(flat)
-        flat /= d.get_world_size()
+        self.tr._allreduce_bucket()
 
     def ranks_seen(self):
         t = self.ones.clone()
@@ -172,6 +171,10 @@ def parse_args(argv=None):
                     help="every timed step also runs the trainer's gradient-bucket all-reduce + KL mean "
                          "(default whenever --gpus > 1)")
     ap.add_argument("--no-grad-allreduce", action="store_true", help="N > 1 without the collective")
+    ap.add_argument("--allreduce-every", type=int, default=3,
+                    help="env steps per gradient all-reduce when the collective is on.  Default 3 = the training ratio "
+                         "with the reference's defaults (train_process.py:21-79: 300 env steps per epoch, then 50 policy "
+                         "+ 50 value optimizer steps, one collective each); 1 = one per env step (worst case)")
     ap.add_argument("--serial-collective", action="store_true",
                     help="issue the collective on the env step's own stream (default: a second HIP stream, so "
                          "that it overlaps the next env step as it would overlap any other compute)")
@@ -179,6 +182,10 @@ def parse_args(argv=None):
                     "rehearse the N > 1 code path where the ranks cannot have a GPU each)")
     ap.add_argument("--all-ranks-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this one GPU (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: initialise torch.distributed even with one rank (with --backend nccl this runs the "
+                         "gradient-bucket collective through RCCL on a single GPU: library, device binding and call "
+                         "sequence are the ones of an N-GPU run)")
     ap.add_argument("--no-cold", action="store_true",
                     help="skip the cache-cold kernel timing (roofline.frac_cold)")
     ap.add_argument("--cold-mb", type=int, default=1024,
@@ -335,7 +342,10 @@ def run_rank(args):
         raise SystemExit("--all-ranks-on-device needs --backend gloo (RCCL wants one GPU per rank)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         dist = sharding.init_process_group(args.backend, dev)  # nccl == RCCL on ROCm
 
     E, N, nm, nb = args.envs, args.drones, args.nm, args.buildings
@@ -350,7 +360,7 @@ def run_rank(args):
                         for t in range(n_act)]).to(dev)
     autoreset = not args.no_autoreset
     env.observe()
-    with_coll = (world > 1 or args.grad_allreduce) and not args.no_grad_allreduce
+    with_coll = (world > 1 or args.grad_allreduce or args.force_dist) and not args.no_grad_allreduce
     bucket = GradBucket(env, dist) if with_coll else None
     torch.cuda.synchronize()
 
@@ -366,11 +376,13 @@ def run_rank(args):
         flush_buf = torch.zeros(max(args.cold_mb, 1) << 20, dtype=torch.uint8, device=dev)
         flush = (lambda: flush_buf.add_(1)) if args.cold_mode == "rw" else (lambda: flush_buf.sum())
 
+    every = max(1, args.allreduce_every)
+
     def one_step(t):
         if flush is not None:
             flush()
         env.step(acts[t % n_act], autoreset=autoreset)
-        if bucket is not None:
+        if bucket is not None and t % every == 0:
             if side is not None:
                 with torch.cuda.stream(side):
                     bucket.step()
@@ -438,7 +450,7 @@ def run_rank(args):
     flags = env.error_flags()
     coll = None
     ranks_seen = 1
-    if world > 1:  # from a real all-reduce, whatever else is switched off
+    if dist is not None:  # from a real all-reduce, whatever else is switched off
         ones = torch.ones(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         ranks_seen = int(round(float(ones.item())))
@@ -450,11 +462,12 @@ def run_rank(args):
             b.record(stream)
         torch.cuda.synchronize()
         coll = dict(ranks_seen=ranks_seen,
-                    backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none (1 rank)",
+                    backend=("nccl (RCCL)" if args.backend == "nccl" else args.backend) if dist is not None else "none (1 rank)",
                     allreduce_us=round(float(np.mean([a.elapsed_time(b) for a, b in ce])) * 1e3, 2),
                     overlapped=side is not None,
-                    bucket_bytes=bucket.nbytes, per_step="ONE all-reduce of the gradient bucket with the KL estimate in its last slot "
-                    "(multi_ppo._allreduce_grads), once per timed env step")
+                    bucket_bytes=bucket.nbytes, env_steps_per_allreduce=every,
+                    per_step="ONE all-reduce of the gradient bucket with the KL estimate in its last slot "
+                    f"(multi_ppo._allreduce_grads) per {every} timed env step(s)")
     elif world > 1:
         coll = dict(ranks_seen=ranks_seen, backend="nccl (RCCL)" if args.backend == "nccl" else args.backend,
                     per_step="none (--no-grad-allreduce)")
@@ -522,7 +535,7 @@ def run_rank(args):
             if elapsed_step_only is not None:
                 coll["value_env_step_only"] = round(total_units / elapsed_step_only, 1)
                 coll["ms_per_step_env_step_only"] = round(elapsed_step_only / K * 1e3, 4)
-                out["config"]["workload"] += ("; + gradient-bucket all-reduce and KL mean per step" +
+                out["config"]["workload"] += (f"; + gradient-bucket all-reduce and KL mean every {every} step(s)" +
                                               (" on a second stream" if side is not None else ""))
             out["collective"] = coll
         if rollout is not None:

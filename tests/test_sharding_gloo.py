@@ -62,8 +62,8 @@ def _bucket_worker(rank, world, port, q):
         E, N, W, device = 2, 3, 102, torch.device("cpu")
     b = bench.GradBucket(Env(), dist)
     for p in b.ac.parameters():
-        p.grad = torch.full_like(p, float(rank + 1))   # rank 0: 1, rank 1: 2 -> mean 1.5
-    b.kl32 += rank                                     # rank 0: 0, rank 1: 1 -> mean 0.5, in the bucket's last slot
+        p.grad.fill_(float(rank + 1))                  # (views of the bucket) rank 0: 1, rank 1: 2 -> mean 1.5
+    b.tr._bucket()[-1] = float(rank)                   # rank 0: 0, rank 1: 1 -> mean 0.5, in the bucket's last slot
     b.step()
     seen = b.ranks_seen()
     g = torch.cat([p.grad.reshape(-1) for p in b.ac.parameters()])
