@@ -157,7 +157,8 @@ __global__ void __launch_bounds__(256) policy_sample_kernel(const PolicySampleAr
     }
   };
   request(0, cur);
-#pragma unroll
+  // (rolled: fully unrolled the compiler hoists every quad's loads and the kernel needs 142 VGPRs = 3 waves per SIMD)
+#pragma unroll 1
   for (int q = 0; q < 8; ++q) {
     if (q + 1 < 8) request(q + 1, nxt);
     float p[4][3];

@@ -167,7 +167,7 @@ class multi_ppo:
         self.fused_rollout = bool(fused_rollout)
         self.rollout_chunk = rollout_chunk  # rows per policy pass of the fused rollout (None / 0: all at once)
         # the rollout's policy GEMMs ([E*N, 128] x [128, 512], [E*N, 256] x [256, 256], bf16) through PyTorch's
-        # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 1 s per shape) and keeps
+        # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 3 s per shape) and keeps
         # the fastest - at 64 x 4096 a 256x256x64 stream-K kernel, 70 us, instead of the heuristic's 84 us
         self.tune_gemms = bool(tune_gemms)
         # key of the counter-based action noise of the fused rollout (rvo3d_policy_sample): per rank
@@ -232,7 +232,8 @@ class multi_ppo:
             import torch.cuda.tunable as tun
             was = tun.is_enabled()
             if not getattr(self, "_tun_set", False):
-                tun.set_max_tuning_duration(1000)
+                tun.set_max_tuning_duration(3000)  # ms per GEMM shape, once per process (two shapes in a rollout)
+                tun.set_max_tuning_iterations(100)
                 if hasattr(tun, "write_file_on_exit"):
                     tun.write_file_on_exit(False)  # results stay in the process
                 else:  # this PyTorch writes its results at exit: into the temp dir, not the cwd
