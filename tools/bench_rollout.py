@@ -17,6 +17,8 @@ ap.add_argument("--policy", default="mlp")
 ap.add_argument("--minibatch", type=int, default=262144)
 ap.add_argument("--amp", action="store_true")
 ap.add_argument("--no-update", action="store_true", help="rollout only (for profiling the loop)")
+ap.add_argument("--no-tune", action="store_true", help="hipBLASLt's heuristic kernels instead of TunableOp's pick "
+                "(a rocprofv3 trace then holds no tuning runs; the GEMMs are ~15 %% slower)")
 args = ap.parse_args()
 E, N, T = args.envs, args.drones, args.steps
 env = BatchedDroneEnv(synthetic_world(E, N, (50, 50, 10)))
@@ -30,7 +32,7 @@ ac = (mlp_ac(env.W) if args.policy == "mlp" else
       rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh,
              torch.nn.Identity, use_gpu=False, rnn_mode="biGRU")).cuda()
 tr = multi_ppo(env, ac, train_epoch=0, steps_per_epoch=T, max_ep_len=500, train_pi_iters=2,
-               train_v_iters=2, target_kl=1e9, minibatch_size=args.minibatch, save_freq=10**9, amp=args.amp)
+               train_v_iters=2, target_kl=1e9, minibatch_size=args.minibatch, save_freq=10**9, amp=args.amp, tune_gemms=not args.no_tune)
 env.reset(); env.observe()
 tr.collect(); tr.buf.get()            # warm-up (allocator, hipBLASLt heuristics)
 torch.cuda.synchronize(); t0 = time.perf_counter()
