@@ -213,13 +213,31 @@ class multi_ppo:
         self.log = []
 
     # ---- rollout ------------------------------------------------------------------------
+    def _fused_mode(self):
+        """How a rollout step runs on the GPU: "heads" - the MLP actor-critic, everything from the last hidden
+        layers on in rvo3d_policy_sample; "direct" - any other actor-critic with the reference's surface
+        (`ac.pi._distribution`, `ac.v`, e.g. the biGRU rnn_ac): its own forward gives mu and v, the kernel
+        samples / rounds / stores; None - the module path of collect() (CPU, or fused_rollout=False)."""
+        if self.device.type != "cuda" or not self.fused_rollout:
+            return None
+        if hasattr(self.ac, "fused_plan"):
+            plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
+            if plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024)):
+                return "heads"
+            return "direct" if hasattr(self.ac, "dist") else None
+        return "direct" if hasattr(getattr(self.ac, "pi", None), "_distribution") else None
+
     def _fused_ok(self):
-        """The fused rollout step (one pass for heads + sampling + stores, one for the bookkeeping) applies
-        to the MLP actor-critic on the GPU; anything else takes the module path of collect()."""
-        if self.device.type != "cuda" or not hasattr(self.ac, "fused_plan") or not self.fused_rollout:
-            return False
-        plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
-        return plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024))
+        return self._fused_mode() is not None
+
+    def _mu_v(self, obs, cnt):
+        """mu (after the output activation) and v of the caller's own network, float32 [B, 3] / [B]."""
+        with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp):
+            if hasattr(self.ac, "dist"):            # mlp_ac with a shape the heads kernel has no instantiation for
+                mu, v = self.ac.dist(obs).mean, self.ac.v(obs)
+            else:                                   # rnn_ac (policy_rnn_ac.py:57-69)
+                mu, v = self.ac.pi._distribution((obs, cnt)).mean, self.ac.v((obs, cnt))
+        return mu.float().contiguous(), v.float().reshape(-1).contiguous()
 
     def _tuned_gemms(self):
         """Context: TunableOp on for the GEMMs issued inside (and back to its previous state after)."""
@@ -273,17 +291,28 @@ class multi_ppo:
         p = lambda t: C.c_void_p(t.data_ptr())
         stream = lambda: C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         since_full_reset = 0
+        mode = self._fused_mode()
+        log_std = self.ac.log_std if hasattr(self.ac, "log_std") else self.ac.pi.log_std
         for t in range(T):
-            plan = self.ac.fused_plan(dt)
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
+            if mode == "direct":
+                mu, v = self._mu_v(x, buf.cnt[t].view(E * N))
+                hd = _lib.PolicyHeads(mu.data_ptr(), v.data_ptr(), mu.stride(0), 1, _lib.RVO3D_F32, 0, 0, 0,
+                                      None, None, None, None, log_std.data_ptr())
+                _lib.check(L.rvo3d_policy_sample(C.byref(hd), E * N, 1.0, self._sample_seed, ac["step"],
+                                                 p(act_t), p(logp_t), p(val_t), None, None, stream()),
+                           "rvo3d_policy_sample")
+                ac["step"] += 1
+                del mu, v
+            plan = self.ac.fused_plan(dt) if mode == "heads" else None
             # (rollout_chunk: the policy can run over the rows in chunks whose activations stay in the 256 MiB
             # Infinity Cache.  Measured at 64 x 4096, bf16: no gain - 422 / 420 / 427 / 555 us per step for all /
             # 131072 / 65536 / 32768 rows per pass; the [rows, 256] x [256, 256] GEMMs take 20 us per 65536 rows
             # either way: they are not bound by HBM.  Off by default.)
             B = E * N
             Cn = B if not self.rollout_chunk else min(B, int(self.rollout_chunk))
-            for r0 in range(0, B, Cn):
+            for r0 in (range(0, B, Cn) if mode == "heads" else ()):
                 n = min(Cn, B - r0)
                 xc = x[r0:r0 + n]
                 if dt != torch.float32:

@@ -162,8 +162,8 @@ def test_rollout_account_matches_the_module_path(E, N):
         assert bool(anyx.item()) == bool(want[4].any())
 
 
-@pytest.mark.parametrize("amp", [False, True])
-def test_fused_rollout_is_a_faithful_rollout(amp):
+@pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (False, "rnn"), (False, "mlp_small")])
+def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     """The fused loop (multi_ppo._collect_fused) on 16 drones x 64 envs: (a) a second env stepped with the
     STORED actions reproduces every stored observation, count and reward bit for bit - the buffer holds
     what the env really did; (b) the stored values are the critic's, the stored log-probabilities and
@@ -173,9 +173,17 @@ def test_fused_rollout_is_a_faithful_rollout(amp):
     world = synthetic_world(E, N, (20, 20, 8), n_points=3, seed=4)
     env = BatchedDroneEnv(world)
     torch.manual_seed(0)
-    ac = mlp_ac(env.W).cuda()
+    if kind == "rnn":   # the reference's architecture (biGRU reader): its own forward, then the "direct" kernel mode
+        from rvo3d_amd.policy import rnn_ac
+
+        class Space:
+            shape = (3,)
+        ac = rnn_ac(None, Space(), 12, 9, 32, (64, 64), (64, 64), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                    use_gpu=False, rnn_mode="biGRU").cuda()
+    else:               # (64, 64): a hidden width the heads kernel has no instantiation for -> "direct" as well
+        ac = mlp_ac(env.W, hidden_sizes=(64, 64) if kind == "mlp_small" else (256, 256)).cuda()
     tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3)
-    assert tr._fused_ok()
+    assert tr._fused_mode() == ("heads" if kind == "mlp" else "direct")
     env.reset(); env.observe()
     mean_ret = tr.collect()
     buf = tr.buf
@@ -202,8 +210,9 @@ def test_fused_rollout_is_a_faithful_rollout(amp):
     # (b) the stored numbers against the module's own float32 forward on the stored observations
     with torch.no_grad():
         x = buf.obs[:T].reshape(-1, env.W)
-        d, _ = ac.pi(x)
-        v = ac.v(x)
+        arg = (x, buf.cnt[:T].reshape(-1)) if kind == "rnn" else x
+        d, _ = ac.pi(arg)
+        v = ac.v(arg)
     tol = 3e-2 if amp else 1e-4  # bf16 GEMMs in the rollout vs the float32 module
     assert torch.allclose(buf.val.reshape(-1), v, atol=tol, rtol=tol)
     z = (buf.act.reshape(-1, 3) - d.mean) / d.stddev   # rounded action: + U(-0.005, 0.005) / std
