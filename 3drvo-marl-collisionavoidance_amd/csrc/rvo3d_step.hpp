@@ -192,6 +192,10 @@ __device__ __forceinline__ void row_fill_pairs(const Params& P, const Lds& L, in
 // the zeros afterwards (after s_waitcnt vmcnt(0): the zeros of its own wave have landed; workgroups
 // of several waves drain before the sweep's second barrier).  The late blocks are written after the
 // sweep as 128-B windows, one per row, from the proprio staged in LDS (part 2 below).
+// Ordering: `s_waitcnt vmcnt(0)` (+ the workgroup barrier for several waves) makes the early zeros land before a
+// kept row is stored over them.  That holds because the waves of a workgroup share one CU's memory pipeline - the
+// library is built WITHOUT threadgroup-split mode (no -mtgsplit: hipcc's default), where waves of a workgroup
+// could sit on different CUs and a store's completion would not order it against another CU's stores.
 // Full workgroups only (the host tabulates the block pattern of a full workgroup, zf_iters > 0:
 // W even, 48 <= W <= 128, rows per workgroup a multiple of 8); the last, partial workgroup of a
 // launch and other widths take the row-pair writer.
