@@ -153,6 +153,7 @@ Pick pick_kernel(const Params& P) {
   }
   // multi-wave workgroups: the compile-time kernels take any N up to their size
   if (P.nw == 2) return {128, true};
+  if (P.nw == 3) return {192, true};
   if (P.nw == 4) return {256, true};
   return {0, false};
 }
@@ -176,7 +177,7 @@ int launch_nw(rvo3d_env* h, const Params& P, hipStream_t s) {
     else if (k.nfix == 32) { if (k.pad) launch_train<MODE, 1, 32, true>(h, P, s); else launch_train<MODE, 1, 32, false>(h, P, s); }
     else if (k.nfix == 16) launch_train<MODE, 1, 16, false>(h, P, s);
     else launch_train<MODE, 1, 0, false>(h, P, s);
-  } else if constexpr (NW == 2 || NW == 4) {
+  } else if constexpr (NW == 2 || NW == 3 || NW == 4) {
     launch_train<MODE, NW, 64 * NW, true>(h, P, s);
   } else {
     launch_train<MODE, NW, 0, false>(h, P, s);
@@ -190,6 +191,7 @@ int launch(rvo3d_env* h, const Params& P, hipStream_t s) {
   switch (P.nw) {
     case 1: return launch_nw<MODE, 1>(h, P, s);
     case 2: return launch_nw<MODE, 2>(h, P, s);
+    case 3: return launch_nw<MODE, 3>(h, P, s);
     case 4: return launch_nw<MODE, 4>(h, P, s);
     default: return launch_nw<MODE, 8>(h, P, s);
   }
@@ -308,11 +310,11 @@ int rvo3d_create(const rvo3d_config* cfg, rvo3d_env** out) {
   // larger envs get one workgroup of ceil(N / 64) waves each.
   const int N = P.N;
   int nw = (N + 63) / 64;
-  P.nw = nw <= 1 ? 1 : (nw <= 2 ? 2 : (nw <= 4 ? 4 : 8));
+  P.nw = nw <= 4 ? nw : 8;  // 1..4 waves: the compile-time kernels for 64 / 128 / 192 / 256 drones; beyond: generic
   int epb = P.nw == 1 ? 64 / N : 1;
   if (epb > P.E) epb = P.E;
-  // nw = 2 / 4: the compile-time kernels for 128 / 256 drones, any N up to that (ghost lanes)
-  const int ring = (P.nw == 2 || P.nw == 4) ? 64 * P.nw : N;
+  // nw = 2 / 3 / 4: the compile-time kernels for 128 / 192 / 256 drones, any N up to that (ghost lanes)
+  const int ring = (P.nw >= 2 && P.nw <= 4) ? 64 * P.nw : N;
   const int threads = P.nw == 1 ? 64 : (int)align_up((size_t)ring, 64);
   size_t lds = rvo3d::lds_bytes(threads, P.nm, epb, ring, P.nw);
 #ifdef RVO3D_DIAG

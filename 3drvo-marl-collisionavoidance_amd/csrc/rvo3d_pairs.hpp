@@ -351,6 +351,24 @@ template <> struct OffsetSet<2> {
   __device__ __forceinline__ void store(uint32_t* g) const { g[0] = (uint32_t)a; g[1] = (uint32_t)(a >> 32); }
   __device__ __forceinline__ int count() const { return __builtin_popcountll(a); }
 };
+template <> struct OffsetSet<3> {  // 96 offsets (192-drone ring): 64 + 32
+  unsigned long long lo;
+  uint32_t hi;
+  __device__ __forceinline__ static OffsetSet load(const uint32_t* g) {
+    return {(unsigned long long)g[0] | ((unsigned long long)g[1] << 32), g[2]};
+  }
+  __device__ __forceinline__ static OffsetSet none() { return {0ull, 0u}; }
+  __device__ __forceinline__ bool any() const { return lo != 0ull || hi != 0u; }
+  __device__ __forceinline__ int lowest() const { return lo != 0ull ? __builtin_ctzll(lo) : 64 + __builtin_ctz(hi); }
+  __device__ __forceinline__ void drop() {
+    if (lo != 0ull) lo &= lo - 1ull; else hi &= hi - 1u;
+  }
+  __device__ __forceinline__ void add(int b, int on) {
+    if (b < 64) lo |= (unsigned long long)(on & 1) << b; else hi |= (uint32_t)(on & 1) << (b - 64);
+  }
+  __device__ __forceinline__ void store(uint32_t* g) const { g[0] = (uint32_t)lo; g[1] = (uint32_t)(lo >> 32); g[2] = hi; }
+  __device__ __forceinline__ int count() const { return __builtin_popcountll(lo) + __builtin_popcount(hi); }
+};
 template <> struct OffsetSet<4> {
   unsigned long long lo, hi;
   __device__ __forceinline__ static OffsetSet load(const uint32_t* g) {

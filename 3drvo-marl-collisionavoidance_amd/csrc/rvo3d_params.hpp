@@ -69,7 +69,7 @@ struct Params {
   float bandn;     // band + t10n: the same start for the "possibly touching" threshold of stage G
   float band;      // fp32 error bound of a squared distance at <= 10.5 m
   // fp32 cone pre-filter (stage X1)
-  int nw;          // ceil(N / 64) rounded up to a power of two: words per request mask
+  int nw;          // ceil(N / 64) (1..4; 8 beyond 256 drones): words per request mask, 32-offset words per drone
   float x1_gap;    // below this d2 - R^2 the cone filter is skipped (pair passes)
   float x1_k2;     // slack factor on K^2
   float x1_cs2;    // (cos-space error bound)^2: dp < 0 and dp^2 > cs2*d2*w2 is surely outside

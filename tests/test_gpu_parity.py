@@ -387,8 +387,9 @@ def test_ragged_sizes(N, E, nm):
                                         (63, 4, "<2, 1, 64, true, true>"), (24, 11, "<2, 1, 32, true, true>"),
                                         (31, 8, "<2, 1, 32, true, true>"), (65, 4, "<2, 2, 128, true, true>"),
                                         (96, 6, "<2, 2, 128, true, true>"), (127, 3, "<2, 2, 128, true, true>"),
-                                        (129, 3, "<2, 4, 256, true, true>"), (200, 4, "<2, 4, 256, true, true>"),
-                                        (255, 2, "<2, 4, 256, true, true>")])
+                                        (129, 3, "<2, 3, 192, true, true>"), (160, 4, "<2, 3, 192, true, true>"),
+                                        (192, 3, "<2, 3, 192, true, true>"), (193, 2, "<2, 4, 256, true, true>"),
+                                        (200, 4, "<2, 4, 256, true, true>"), (255, 2, "<2, 4, 256, true, true>")])
 def test_padded_compile_time_kernels(N, E, kernel):
     """Envs smaller than the compile-time ring of their kernel (round 3): the lanes beyond N are ghost drones
     parked at infinity.  Dense worlds (many pairs across the ring's seam, resets every few steps), both reset

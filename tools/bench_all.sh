@@ -22,3 +22,5 @@ run --envs 2731 --drones 96 --map 60 60 10
 run --envs 5461 --drones 48 --map 45 45 10
 run --envs 2048 --drones 100 --map 60 60 10
 run --envs 1310 --drones 200 --map 90 90 10
+run --envs 1638 --drones 160 --map 80 80 10
+run --envs 1365 --drones 192 --map 85 85 10

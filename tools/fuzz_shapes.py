@@ -28,7 +28,7 @@ t_all = time.time()
 for c in range(cases):
     kind = rng.integers(6)
     N = int([rng.integers(2, 17), rng.integers(17, 65), rng.choice([16, 32, 64]), rng.integers(65, 129),
-             rng.choice([128, 256]), rng.integers(129, 301)][kind])
+             rng.choice([128, 192, 256]), rng.integers(129, 301)][kind])
     budget = 6000 if N <= 64 else 3000
     E = int(max(1, min(rng.integers(1, 40), budget // N)))
     nm = int(rng.choice([0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 14]))
