@@ -652,6 +652,37 @@ int rvo3d_policy_sample(const rvo3d_policy_heads* hd, int64_t rows, float std_fa
   RVO3D_API_END
 }
 
+int rvo3d_reader_first_step(const rvo3d_gru_reader* rd, const float* obs, int64_t obs_ld, int64_t rows, void* feat,
+                            int32_t feat_dtype, int64_t feat_ld, void* stream) {
+  RVO3D_API_BEGIN
+  if (!rd || !obs || !feat || !rd->w_ih_f || !rd->b_ih_f || !rd->b_hh_f || !rd->ln_w || !rd->ln_b)
+    return fail(RVO3D_ERR_INVALID, "null pointer");
+  if ((rd->w_ih_r != nullptr) != (rd->b_ih_r != nullptr) || (rd->w_ih_r != nullptr) != (rd->b_hh_r != nullptr))
+    return fail(RVO3D_ERR_INVALID, "the reverse direction needs all three of w_ih_r / b_ih_r / b_hh_r");
+  if (rd->hidden < 64 || rd->hidden > 256 || rd->hidden % 64 != 0 || rd->in_dim != 9 || rd->state_dim < 0 ||
+      rd->state_dim > rvo3d::kReaderMaxSd)
+    return fail(RVO3D_ERR_INVALID, "hidden must be 64 / 128 / 192 / 256, in_dim 9, state_dim <= 32");
+  if (feat_dtype != RVO3D_F32 && feat_dtype != RVO3D_BF16) return fail(RVO3D_ERR_INVALID, "feat_dtype must be RVO3D_F32 or RVO3D_BF16");
+  if (rows < 0 || obs_ld < rd->state_dim + rd->in_dim || feat_ld < rd->state_dim + rd->hidden)
+    return fail(RVO3D_ERR_INVALID, "rows / row strides too small");
+  if (feat_dtype == RVO3D_BF16 && ((reinterpret_cast<uintptr_t>(feat) & 7) || (feat_ld & 3)))
+    return fail(RVO3D_ERR_INVALID, "bf16 features: feat 8-byte aligned, feat_ld a multiple of 4");
+  if (rows == 0) return RVO3D_OK;
+  rvo3d::ReaderArgs A;
+  A.w_ih_f = rd->w_ih_f; A.b_ih_f = rd->b_ih_f; A.b_hh_f = rd->b_hh_f;
+  A.w_ih_r = rd->w_ih_r; A.b_ih_r = rd->b_ih_r; A.b_hh_r = rd->b_hh_r;
+  A.ln_w = rd->ln_w; A.ln_b = rd->ln_b; A.H = rd->hidden; A.IN = rd->in_dim; A.SD = rd->state_dim; A.eps = rd->ln_eps;
+  A.obs = obs; A.obs_ld = obs_ld; A.rows = rows; A.feat = feat; A.feat_bf16 = feat_dtype == RVO3D_BF16; A.feat_ld = feat_ld;
+  const int64_t groups = (rows + rvo3d::kReaderRows - 1) / rvo3d::kReaderRows;
+  // a few workgroups per CU, each looping over row groups: the unit's weights are loaded once per workgroup
+  const unsigned grid = (unsigned)(groups < 256 * 8 ? groups : 256 * 8);
+  hipLaunchKernelGGL((rvo3d::reader_first_step_kernel<9>), dim3(grid), dim3((unsigned)rd->hidden), 0,
+                     static_cast<hipStream_t>(stream), A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
 int rvo3d_rollout_account(int32_t E, int32_t N, const float* reward, const uint8_t* done, const uint8_t* finish,
                           int32_t sanitize, int32_t max_ep_len, int32_t epoch_end, float* rew_slot, float* ep_ret,
                           int32_t* ep_len, uint8_t* cut_slot, uint8_t* extra_mask, double* sums, int32_t* any_extra,

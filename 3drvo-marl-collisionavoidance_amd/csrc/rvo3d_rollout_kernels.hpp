@@ -275,4 +275,176 @@ __global__ void __launch_bounds__(512) rollout_account_kernel(const AccountArgs 
   }
 }
 
+// ---- rnn_Reader for one-step sequences (policy_rnn_ac.py:75-127: biGRU over the VO rows, sum of the two final hidden
+//      states, concat with the proprioceptive part, LayerNorm) ----
+// In a rollout nearly every drone has zero or one VO row, and a GRU over a one-step sequence from h = 0 is one cell
+// evaluation without the recurrent GEMM: r = s(W_ir x + b_ir + b_hr), z = s(W_iz x + b_iz + b_hz),
+// n = tanh(W_in x + b_in + r b_hn), h = (1 - z) n.  With in_dim = 9 that is 54 multiply-adds per hidden unit and
+// direction: far too little for a GEMM (K = 9) and, issued as PyTorch ops, a dozen elementwise passes over [rows, 3 H]
+// float32 temporaries (2.9 ms per 262144 rows).  Here: one thread per hidden unit with its 2 x 3 x in_dim weights in
+// registers, eight rows per trip (their 21 leading floats staged in LDS and read as broadcasts), the LayerNorm's two
+// row reductions done for the eight rows at once; the row's features leave as the (padded) A operand of the first MLP
+// layer.  Reads 84 B and writes (state_dim + H) elements per row: compute-bound on the transcendentals (~0.2 ms).
+// Rows with more than one VO row are recomputed by the caller (PyTorch, a small gathered batch) afterwards.
+struct ReaderArgs {
+  const float *w_ih_f, *b_ih_f, *b_hh_f;  // [3H][IN], [3H], [3H]   (nn.GRU: gates r, z, n)
+  const float *w_ih_r, *b_ih_r, *b_hh_r;  // reverse direction or null
+  const float *ln_w, *ln_b;               // [SD + H]
+  int32_t H, IN, SD;
+  float eps;
+  const float* obs; int64_t obs_ld, rows;
+  void* feat; int32_t feat_bf16; int64_t feat_ld;
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+constexpr int kReaderRows = 8;   // rows per trip
+constexpr int kReaderMaxIn = 16; // in_dim <= 16
+constexpr int kReaderMaxSd = 32; // state_dim <= 32
+
+template <int IN>
+__global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs A) {
+  __shared__ float s_in[kReaderRows][kReaderMaxSd + kReaderMaxIn];
+  __shared__ float s_red[kReaderRows][4];
+  __shared__ float s_stat[2][kReaderRows];  // mean, 1 / sqrt(var + eps) of the eight rows
+  __shared__ __attribute__((aligned(16))) uint16_t s_out[kReaderRows][kReaderMaxSd + 256];  // bf16 rows on their way out
+  const int u = threadIdx.x, H = A.H, SD = A.SD, D = SD + H;
+  const int lane = u & 63, wv = u >> 6, nwv = (H + 63) >> 6;
+  const bool bi = A.w_ih_r != nullptr;
+  // this unit's weights: [dir][gate][IN]; biases folded where the cell allows it
+  float w[2][3][IN], c_r[2], c_z[2], b_in[2], b_hn[2];
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* wih = dir ? A.w_ih_r : A.w_ih_f;
+    const float* bih = dir ? A.b_ih_r : A.b_ih_f;
+    const float* bhh = dir ? A.b_hh_r : A.b_hh_f;
+    const bool on = dir == 0 || bi;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int k = 0; k < IN; ++k) w[dir][g][k] = on ? wih[(size_t)(g * H + u) * IN + k] : 0.f;
+    c_r[dir] = on ? bih[u] + bhh[u] : 0.f;
+    c_z[dir] = on ? bih[H + u] + bhh[H + u] : 0.f;
+    b_in[dir] = on ? bih[2 * H + u] : 0.f;
+    b_hn[dir] = on ? bhh[2 * H + u] : 0.f;
+  }
+  const float lw = A.ln_w[SD + u], lb = A.ln_b[SD + u];
+  const float lw0 = u < SD ? A.ln_w[u] : 0.f, lb0 = u < SD ? A.ln_b[u] : 0.f;
+  const int64_t ngroups = (A.rows + kReaderRows - 1) / kReaderRows;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t row0 = grp * kReaderRows;
+    __syncthreads();  // the previous trip's readers are done with the LDS buffers
+    for (int i = u; i < kReaderRows * (SD + IN); i += H) {
+      const int r = i / (SD + IN), k = i - r * (SD + IN);
+      const int64_t row = row0 + r < A.rows ? row0 + r : A.rows - 1;
+      s_in[r][k] = A.obs[row * A.obs_ld + k];
+    }
+    __syncthreads();
+    float h[kReaderRows];
+    // Packed fp32 (v_pk_fma_f32) across GATES, not rows - the weights pair up as they sit in registers ((r, z) of a
+    // direction; n of the two directions), only the row's nine inputs are splatted: 27 instead of 54 multiply-add
+    // instructions per row.  Two rows per loop trip (fully unrolled over the eight rows: 176 VGPRs = two waves per
+    // SIMD).  Per unit, row and direction five transcendentals instead of six: (1 - z) n with z = 1 / (1 + e_z),
+    // n = tanh(a) = (1 - e_n) / (1 + e_n), e_z = exp(-g_z), e_n = exp(-2 a) is e_z (1 - e_n) / ((1 + e_z)(1 + e_n)):
+    // one reciprocal for both.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll 2
+    for (int r = 0; r < kReaderRows; ++r) {
+      v2f rz[2] = {{c_r[0], c_z[0]}, {c_r[1], c_z[1]}}, nn = {b_in[0], b_in[1]};
+#pragma unroll
+      for (int k = 0; k < IN; ++k) {
+        const float xk = s_in[r][SD + k];
+        const v2f xx = {xk, xk};
+        rz[0] = __builtin_elementwise_fma((v2f){w[0][0][k], w[0][1][k]}, xx, rz[0]);
+        rz[1] = __builtin_elementwise_fma((v2f){w[1][0][k], w[1][1][k]}, xx, rz[1]);
+        nn = __builtin_elementwise_fma((v2f){w[0][2][k], w[1][2][k]}, xx, nn);
+      }
+      float hs = 0.f;
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir) {
+        const float rg = fast_sigmoid(rz[dir].x);
+        const float a = (dir ? nn.y : nn.x) + rg * b_hn[dir];
+        // clamped exponents: exp(88) overflows float32 to inf and inf / inf is NaN; beyond +-30 the cell saturates anyway
+        const float ez = __expf(-__builtin_fmaxf(__builtin_fminf(rz[dir].y, 30.f), -30.f));
+        const float en = __expf(-2.0f * __builtin_fmaxf(__builtin_fminf(a, 15.f), -15.f));
+        const float hd = ez * (1.0f - en) * __frcp_rn((1.0f + ez) * (1.0f + en));
+        if (dir == 0 || bi) hs += hd;
+      }
+      h[r] = hs;
+    }
+    // LayerNorm (biased variance, eps inside the root: torch.nn.LayerNorm), two passes over the eight rows: wave
+    // sums of the hidden part, then thread r < 8 adds the waves' partial sums and the row's proprioceptive part
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int r = 0; r < kReaderRows; ++r) {
+        const float m = pass == 0 ? 0.f : s_stat[0][r];
+        float v = pass == 0 ? h[r] : (h[r] - m) * (h[r] - m);
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
+        if (lane == 0) s_red[r][wv] = v;
+      }
+      __syncthreads();
+      if (u < kReaderRows) {
+        float t = 0.f;
+        for (int q = 0; q < nwv; ++q) t += s_red[u][q];
+        if (pass == 0) {
+          for (int k = 0; k < SD; ++k) t += s_in[u][k];
+          s_stat[0][u] = t / (float)D;
+        } else {
+          const float m = s_stat[0][u];
+          for (int k = 0; k < SD; ++k) { const float d = s_in[u][k] - m; t += d * d; }
+          s_stat[1][u] = __frsqrt_rn(t / (float)D + A.eps);
+        }
+      }
+      __syncthreads();
+    }
+    if (A.feat_bf16 && (D & 3) == 0) {
+      // bf16 rows leave through LDS: a thread storing its own 2 bytes per row makes 128-byte store instructions of
+      // byte-masked dwords (the kernel spent half its time there); staged, the trip's eight rows go out as 8-byte
+      // chunks, 512 B per store instruction (D * 2 bytes per row is a multiple of 8, the row stride of 16)
+#pragma unroll
+      for (int r = 0; r < kReaderRows; ++r) {
+        const float mean = s_stat[0][r], rstd = s_stat[1][r];
+        s_out[r][SD + u] = f32_to_bf16_rne((h[r] - mean) * rstd * lw + lb);
+        if (u < SD) s_out[r][u] = f32_to_bf16_rne((s_in[r][u] - mean) * rstd * lw0 + lb0);
+      }
+      __syncthreads();
+      const int cpr = D >> 2;  // 8-byte chunks per row
+      for (int i = u; i < kReaderRows * cpr; i += H) {
+        const int r = i / cpr, c = i - r * cpr;
+        const int64_t row = row0 + r;
+        if (row < A.rows)
+          *reinterpret_cast<uint2*>(static_cast<uint16_t*>(A.feat) + row * A.feat_ld + 4 * c) =
+              *reinterpret_cast<const uint2*>(&s_out[r][4 * c]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kReaderRows; ++r) {
+        const int64_t row = row0 + r;
+        if (row >= A.rows) break;
+        const float mean = s_stat[0][r], rstd = s_stat[1][r];
+        const float y = (h[r] - mean) * rstd * lw + lb;
+        const float y0 = u < SD ? (s_in[r][u] - mean) * rstd * lw0 + lb0 : 0.f;
+        if (A.feat_bf16) {
+          uint16_t* o = static_cast<uint16_t*>(A.feat) + row * A.feat_ld;
+          o[SD + u] = f32_to_bf16_rne(y);
+          if (u < SD) o[u] = f32_to_bf16_rne(y0);
+        } else {
+          float* o = static_cast<float*>(A.feat) + row * A.feat_ld;
+          o[SD + u] = y;
+          if (u < SD) o[u] = y0;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace rvo3d

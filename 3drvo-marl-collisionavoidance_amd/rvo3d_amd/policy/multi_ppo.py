@@ -224,8 +224,9 @@ class multi_ppo:
             plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
             if plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024)):
                 return "heads"
-            return "direct" if hasattr(self.ac, "dist") else None
-        return "direct" if hasattr(getattr(self.ac, "pi", None), "_distribution") else None
+        if hasattr(self.ac, "dist") or hasattr(getattr(self.ac, "pi", None), "_distribution"):
+            return "direct"
+        return None
 
     def _fused_ok(self):
         return self._fused_mode() is not None
@@ -236,7 +237,13 @@ class multi_ppo:
             if hasattr(self.ac, "dist"):            # mlp_ac with a shape the heads kernel has no instantiation for
                 mu, v = self.ac.dist(obs).mean, self.ac.v(obs)
             else:                                   # rnn_ac (policy_rnn_ac.py:57-69)
-                mu, v = self.ac.pi._distribution((obs, cnt)).mean, self.ac.v((obs, cnt))
+                pi, vf = self.ac.pi, self.ac.v
+                if getattr(pi, "rnn_reader", None) is not None and pi.rnn_reader is getattr(vf, "rnn_reader", None):
+                    # actor and critic share ONE reader instance (policy_rnn_ac.py:46-54): read once
+                    feat = pi.rnn_reader.forward_batch(obs, torch.clamp(cnt.to(torch.int64), min=1))
+                    mu, v = pi.net_out(feat), vf.v_net(feat).squeeze(-1)
+                else:
+                    mu, v = pi._distribution((obs, cnt)).mean, vf((obs, cnt))
         return mu.float().contiguous(), v.float().reshape(-1).contiguous()
 
     def _tuned_gemms(self):
@@ -292,7 +299,7 @@ class multi_ppo:
         stream = lambda: C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         since_full_reset = 0
         mode = self._fused_mode()
-        log_std = self.ac.log_std if hasattr(self.ac, "log_std") else self.ac.pi.log_std
+        log_std = self.ac.log_std
         for t in range(T):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
@@ -314,14 +321,9 @@ class multi_ppo:
             Cn = B if not self.rollout_chunk else min(B, int(self.rollout_chunk))
             for r0 in (range(0, B, Cn) if mode == "heads" else ()):
                 n = min(Cn, B - r0)
-                xc = x[r0:r0 + n]
-                if dt != torch.float32:
-                    # ONE kernel: cast + copy into the zero-padded [rows, Kp] operand of the first-layer GEMM
-                    xp = ac.get("xp")
-                    if xp is None or xp.shape != (Cn, plan["k_pad"]) or xp.dtype != dt:
-                        xp = ac["xp"] = torch.zeros((Cn, plan["k_pad"]), dtype=dt, device=self.device)
-                    xp[:n, :env.W].copy_(xc)
-                    xc = xp[:n]
+                # the first layer's A operand: mlp_ac - the observation cast into a zero-padded buffer (ONE kernel);
+                # rnn_ac - the reader's features (rvo3d_reader_first_step + the few rows with several VO rows)
+                xc = self.ac.prepare_input(x[r0:r0 + n], buf.cnt[t].view(E * N)[r0:r0 + n], plan, ac)
                 with torch.no_grad(), self._tuned_gemms():
                     hp, hv = self.ac.hidden_pair(xc, plan)
                 hd = _lib.PolicyHeads(hp.data_ptr(), hv.data_ptr(), hp.stride(0), hv.stride(0),

@@ -46,6 +46,60 @@ def _cast_cached(p, dtype):
     return t
 
 
+def _mlp_pair_plan(pi_net, v_net, dtype):
+    """Inference plan for an actor / critic pair of ReLU MLPs of equal depth and widths (None otherwise): the two
+    first layers concatenated into ONE [K -> 2 H1] GEMM (K zero-padded to a multiple of 64 in reduced precision:
+    measured, [262144, 102] x [102, 512] bf16: 130 us; K = 128: 89 us), the deeper hidden layers per net, the two heads
+    as float32 rows for rvo3d_policy_sample."""
+    pl = [m for m in pi_net if isinstance(m, nn.Linear)]
+    vl = [m for m in v_net if isinstance(m, nn.Linear)]
+    pa = [m for m in pi_net if not isinstance(m, nn.Linear)]
+    va = [m for m in v_net if not isinstance(m, nn.Linear)]
+    if (len(pl) != len(vl) or len(pl) < 2 or not all(isinstance(m, nn.ReLU) for m in pa[:-1] + va[:-1])
+            or not isinstance(pa[-1], (nn.Tanh, nn.Identity)) or not isinstance(va[-1], nn.Identity)
+            or pl[0].out_features != vl[0].out_features or pl[-1].in_features != vl[-1].in_features
+            or pl[0].in_features != vl[0].in_features or pl[-1].out_features != 3 or vl[-1].out_features != 1):
+        return None
+    with torch.no_grad():
+        W = pl[0].in_features
+        Kp = W if dtype == torch.float32 else (W + 63) // 64 * 64
+        w1 = torch.zeros((pl[0].out_features + vl[0].out_features, Kp), dtype=dtype, device=pl[0].weight.device)
+        w1[:, :W] = torch.cat([pl[0].weight, vl[0].weight], 0).to(dtype)
+        return dict(
+            w1=w1, k_in=W, k_pad=Kp,                                                      # [2 H1, Kp]
+            b1=torch.cat([pl[0].bias, vl[0].bias], 0).to(dtype).contiguous(),
+            mid=[(p.weight.to(dtype).contiguous(), p.bias.to(dtype).contiguous(),
+                  v.weight.to(dtype).contiguous(), v.bias.to(dtype).contiguous()) for p, v in zip(pl[1:-1], vl[1:-1])],
+            w_pi=pl[-1].weight.detach().float().contiguous(), b_pi=pl[-1].bias.detach().float().contiguous(),
+            w_v=vl[-1].weight.detach().float().reshape(-1).contiguous(), b_v=vl[-1].bias.detach().float().contiguous(),
+            h1=pl[0].out_features, hidden=pl[-1].in_features, tanh=isinstance(pa[-1], nn.Tanh))
+
+
+def _hidden_pair(x, plan):
+    """(actor hidden, critic hidden) [B, H] for rvo3d_policy_sample: ONE GEMM for the two first layers (bias + ReLU
+    in its epilogue), then one GEMM per net and further hidden layer, each reading its half of the previous output in
+    place (row stride 2 H: no copies)."""
+    h = torch._addmm_activation(plan["b1"], x, plan["w1"].t(), use_gelu=False)            # [B, 2 H1]
+    H1 = plan["h1"]
+    hp, hv = h[:, :H1], h[:, H1:]
+    for wp, bp, wv, bv in plan["mid"]:
+        hp = torch._addmm_activation(bp, hp, wp.t(), use_gelu=False)
+        hv = torch._addmm_activation(bv, hv, wv.t(), use_gelu=False)
+    return hp, hv
+
+
+def _plan_cached(module, dtype, build):
+    """`build()` once per (dtype, parameter versions, parameter storages) of `module`."""
+    params = list(module.parameters())
+    key = (dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+    hit = getattr(module, "_plan", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    plan = build()
+    module._plan = (key, plan)
+    return plan
+
+
 def mlp(sizes, activation, output_activation=nn.Identity):  # policy_rnn_ac.py:10-17
     layers = []
     for j in range(len(sizes) - 1):
@@ -112,8 +166,31 @@ class rnn_Reader(nn.Module):  # policy_rnn_ac.py:75-168
             h = torch.where((lens > t).unsqueeze(1), hn, h)
         return h
 
+    def _gru_first(self, xt, suffix):
+        """One GRU cell step from h = 0 (the whole recurrence of a row with ONE valid VO row): with h = 0 the
+        hidden-side pre-activation is its bias alone - no [B, H] x [H, 3H] GEMM - and hn = (1 - z) n.  Bit for
+        bit what _gru_dir computes for such a row (b_hh + 0 W = b_hh, z * 0 = 0)."""
+        r = self.rnn_net
+        w_ih = getattr(r, "weight_ih_l0" + suffix)
+        b_ih, b_hh = getattr(r, "bias_ih_l0" + suffix), getattr(r, "bias_hh_l0" + suffix)
+        gi = torch.addmm(b_ih, xt, w_ih.t())
+        i_r, i_z, i_n = gi.chunk(3, 1)
+        h_r, h_z, h_n = b_hh.chunk(3, 0)
+        rg = torch.sigmoid(i_r + h_r)
+        zg = torch.sigmoid(i_z + h_z)
+        ng = torch.tanh(i_n + rg * h_n)
+        return (1 - zg) * ng
+
     def forward_batch(self, obs, lens):
-        """obs [B, state_dim + input_dim*S] padded; lens [B] >= 1."""
+        """obs [B, state_dim + input_dim*S] padded; lens [B] >= 1.
+
+        In a rollout nearly every drone has zero or one VO row (lens == 1; 0.5 % of the rows have more at the
+        benchmark's density), and a one-step sequence from h = 0 needs no recurrent GEMM at all.  So: the one-step
+        result for every row (two [B, 9] x [9, 3H] GEMMs and a handful of elementwise passes), then the masked
+        unrolled recurrence over the S slots only for the rows with lens > 1, gathered into a small batch and
+        written back.  The same function of the valid rows as before (and as pack_padded_sequence in the
+        reference, policy_rnn_ac.py:129-168); at 262144 rows x 10 slots it replaces twenty [B, 256] x [256, 768]
+        GEMMs per forward (103 ms in fp32) by two [B, 9] x [9, 768] ones."""
         B = obs.shape[0]
         robot = obs[:, :self.state_dim]
         S = (obs.shape[1] - self.state_dim) // self.input_dim
@@ -125,9 +202,19 @@ class rnn_Reader(nn.Module):  # policy_rnn_ac.py:75-168
             _, (hn, _) = self.rnn_net(packed)
             hnv = hn[0]
         else:
-            hnv = self._gru_dir(x, lens, "", False)
-            if self.mode == "biGRU":  # sum of the two directions (policy_rnn_ac.py:121-122)
-                hnv = hnv + self._gru_dir(x, lens, "_reverse", True)
+            bi = self.mode == "biGRU"
+            x0 = x[:, 0]
+            hnv = self._gru_first(x0, "")
+            if bi:  # sum of the two directions (policy_rnn_ac.py:121-122); a one-step sequence reversed is itself
+                hnv = hnv + self._gru_first(x0, "_reverse")
+            if S > 1:
+                idx = torch.nonzero(lens > 1).flatten()   # (one host synchronisation per forward)
+                if idx.numel() > 0:
+                    xs, ls = x.index_select(0, idx), lens.index_select(0, idx)
+                    hs = self._gru_dir(xs, ls, "", False)
+                    if bi:
+                        hs = hs + self._gru_dir(xs, ls, "_reverse", True)
+                    hnv = hnv.index_copy(0, idx, hs.to(hnv.dtype))
         return self.ln(torch.cat((robot, hnv), 1))
 
     # reference names
@@ -214,6 +301,64 @@ class rnn_ac(nn.Module):  # policy_rnn_ac.py:31-72
         self.v = Critic(obs_dim, hidden_sizes_v, activation, output_activation_v, rnn_reader=rnn,
                         use_gpu=use_gpu)
 
+    # ---- rollout fast path (rvo3d_amd.policy.multi_ppo._collect_fused, "heads" mode) ----
+    def fused_plan(self, dtype):
+        """The reader's weights as rvo3d_reader_first_step wants them (float32) + the MLP pair plan of actor and critic
+        on the reader's features; None when the architecture has no fast path (LSTM reader, separate readers, a hidden
+        width or input width the kernel has no instantiation for, non-ReLU stacks)."""
+        def build():
+            r = self.pi.rnn_reader
+            if (r is None or r is not self.v.rnn_reader or r.mode not in ("GRU", "biGRU") or r.input_dim != 9
+                    or r.state_dim > 32 or r.hidden_dim not in (64, 128, 192, 256)):
+                return None
+            plan = _mlp_pair_plan(self.pi.net_out, self.v.v_net, dtype)
+            if plan is None or plan["k_in"] != r.state_dim + r.hidden_dim:
+                return None
+            g = r.rnn_net
+            f32 = lambda t: t.detach().float().contiguous()
+            plan["reader"] = dict(
+                w_ih_f=f32(g.weight_ih_l0), b_ih_f=f32(g.bias_ih_l0), b_hh_f=f32(g.bias_hh_l0),
+                w_ih_r=f32(g.weight_ih_l0_reverse) if r.mode == "biGRU" else None,
+                b_ih_r=f32(g.bias_ih_l0_reverse) if r.mode == "biGRU" else None,
+                b_hh_r=f32(g.bias_hh_l0_reverse) if r.mode == "biGRU" else None,
+                ln_w=f32(r.ln.weight), ln_b=f32(r.ln.bias), eps=float(r.ln.eps))
+            return plan
+        return _plan_cached(self, dtype, build)
+
+    def prepare_input(self, obs, cnt, plan, cache):
+        """The reader's features [rows, Kp] as the A operand of the first MLP layer: rvo3d_reader_first_step for every
+        row (one GRU cell step per direction from h = 0, direction sum, concat, LayerNorm: exact for rows with at most
+        one VO row), then the rows with MORE than one VO row - 0.5 % at the benchmark's density - again through the
+        module's own masked recurrence, gathered into a small batch (one host synchronisation for their indices)."""
+        import ctypes as C
+        from .. import _lib
+        r, rd = self.pi.rnn_reader, plan["reader"]
+        dt = plan["w1"].dtype
+        B = obs.shape[0]
+        feat = cache.get("feat")
+        if feat is None or feat.shape[0] < B or feat.shape[1] != plan["k_pad"] or feat.dtype != dt:
+            feat = cache["feat"] = torch.zeros((B, plan["k_pad"]), dtype=dt, device=obs.device)
+        pp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        st = _lib.GruReader(pp(rd["w_ih_f"]), pp(rd["b_ih_f"]), pp(rd["b_hh_f"]), pp(rd["w_ih_r"]), pp(rd["b_ih_r"]),
+                            pp(rd["b_hh_r"]), pp(rd["ln_w"]), pp(rd["ln_b"]), r.hidden_dim, r.input_dim, r.state_dim,
+                            rd["eps"])
+        _lib.check(_lib.lib().rvo3d_reader_first_step(
+            C.byref(st), pp(obs), obs.stride(0), B, pp(feat), _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32,
+            feat.stride(0), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)), "rvo3d_reader_first_step")
+        idx = torch.nonzero(cnt > 1).flatten()
+        if idx.numel() > 0:
+            with torch.no_grad():
+                full = r.forward_batch(obs.index_select(0, idx), cnt.index_select(0, idx).to(torch.int64))
+            feat[:B, :full.shape[1]].index_copy_(0, idx, full.to(dt))
+        return feat[:B]
+
+    def hidden_pair(self, x, plan):
+        return _hidden_pair(x, plan)
+
+    @property
+    def log_std(self):
+        return self.pi.log_std
+
     def step_tensors(self, obs, std_factor=1):
         """Batched, stays on the device: (a, v, logp) tensors."""
         with torch.no_grad():
@@ -291,53 +436,24 @@ class mlp_ac(nn.Module):
 
     # ---- rollout fast path: everything up to the last hidden layers, merged where the two nets allow ----
     def fused_plan(self, dtype):
-        """Weights of the inference plan of `hidden_pair`, cached per parameter version (an optimizer step
-        rebuilds them): the two first layers concatenated into ONE [W -> 2 H1] GEMM, the deeper hidden
-        layers per net, and the two heads as float32 rows for rvo3d_policy_sample.  None when the stacks
-        are not ReLU MLPs of equal depth (the caller then takes the module path)."""
-        pl = [m for m in self.pi_net if isinstance(m, nn.Linear)]
-        vl = [m for m in self.v_net if isinstance(m, nn.Linear)]
-        pa = [m for m in self.pi_net if not isinstance(m, nn.Linear)]
-        va = [m for m in self.v_net if not isinstance(m, nn.Linear)]
-        if (len(pl) != len(vl) or len(pl) < 2 or not all(isinstance(m, nn.ReLU) for m in pa[:-1] + va[:-1])
-                or not isinstance(pa[-1], (nn.Tanh, nn.Identity)) or not isinstance(va[-1], nn.Identity)
-                or pl[0].out_features != vl[0].out_features or pl[-1].in_features != vl[-1].in_features):
-            return None
-        params = list(self.parameters())
-        key = (dtype, tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
-        hit = getattr(self, "_plan", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        with torch.no_grad():
-            W = pl[0].in_features
-            # reduced-precision GEMMs want K a multiple of 64 (measured, [262144, 102] x [102, 512] bf16:
-            # 130 us; with K padded to 128: 89 us): the caller casts the observation into a zero-padded
-            # [B, Kp] buffer and the first-layer weights get Kp - W zero columns
-            Kp = W if dtype == torch.float32 else (W + 63) // 64 * 64
-            w1 = torch.zeros((pl[0].out_features + vl[0].out_features, Kp), dtype=dtype, device=pl[0].weight.device)
-            w1[:, :W] = torch.cat([pl[0].weight, vl[0].weight], 0).to(dtype)
-            plan = dict(
-                w1=w1, k_in=W, k_pad=Kp,                                                      # [2 H1, Kp]
-                b1=torch.cat([pl[0].bias, vl[0].bias], 0).to(dtype).contiguous(),
-                mid=[(p.weight.to(dtype).contiguous(), p.bias.to(dtype).contiguous(),
-                      v.weight.to(dtype).contiguous(), v.bias.to(dtype).contiguous()) for p, v in zip(pl[1:-1], vl[1:-1])],
-                w_pi=pl[-1].weight.detach().float().contiguous(), b_pi=pl[-1].bias.detach().float().contiguous(),
-                w_v=vl[-1].weight.detach().float().reshape(-1).contiguous(), b_v=vl[-1].bias.detach().float().contiguous(),
-                h1=pl[0].out_features, hidden=pl[-1].in_features, tanh=isinstance(pa[-1], nn.Tanh))
-        self._plan = (key, plan)
-        return plan
+        """Weights of the inference plan of `hidden_pair` (see _mlp_pair_plan), cached per parameter version (an
+        optimizer step rebuilds them); None when the stacks are not ReLU MLPs of equal shape (the caller then takes
+        the module path)."""
+        return _plan_cached(self, dtype, lambda: _mlp_pair_plan(self.pi_net, self.v_net, dtype))
+
+    def prepare_input(self, obs, cnt, plan, cache):
+        """The A operand of the first-layer GEMM: the observation itself (float32) or - ONE kernel - its cast into a
+        zero-padded [rows, Kp] buffer kept in `cache`."""
+        if plan["w1"].dtype == torch.float32:
+            return obs
+        xp = cache.get("xp")
+        if xp is None or xp.shape[0] < obs.shape[0] or xp.shape[1] != plan["k_pad"] or xp.dtype != plan["w1"].dtype:
+            xp = cache["xp"] = torch.zeros((obs.shape[0], plan["k_pad"]), dtype=plan["w1"].dtype, device=obs.device)
+        xp[:obs.shape[0], :obs.shape[1]].copy_(obs)
+        return xp[:obs.shape[0]]
 
     def hidden_pair(self, x, plan):
-        """(actor hidden, critic hidden) [B, H] views for rvo3d_policy_sample: ONE GEMM for the two first
-        layers (bias + ReLU in its epilogue), then one GEMM per net and further hidden layer, each reading
-        its half of the previous output in place (row stride 2 H: no copies)."""
-        h = torch._addmm_activation(plan["b1"], x, plan["w1"].t(), use_gelu=False)            # [B, 2 H1]
-        H1 = plan["h1"]
-        hp, hv = h[:, :H1], h[:, H1:]
-        for wp, bp, wv, bv in plan["mid"]:
-            hp = torch._addmm_activation(bp, hp, wp.t(), use_gelu=False)
-            hv = torch._addmm_activation(bv, hv, wv.t(), use_gelu=False)
-        return hp, hv
+        return _hidden_pair(x, plan)
 
     def step_tensors(self, obs, std_factor=1):
         with torch.no_grad():

@@ -164,6 +164,25 @@ int rvo3d_policy_sample(const rvo3d_policy_heads *heads, int64_t rows, float std
                         uint64_t step, float *act, float *logp, float *val, float *dbg_mu,
                         float *dbg_raw, void *stream);
 
+/* rnn_Reader.obs_rnn (train/policy/policy_rnn_ac.py:75-127) for observations with AT MOST ONE velocity-obstacle row
+ * - nearly all of a rollout's -: the (bi)GRU over a one-step sequence from h = 0 (one cell evaluation per direction,
+ * no recurrent product), the sum of the two directions, the concatenation with the proprioceptive part and the
+ * LayerNorm, in one pass.  obs [rows][obs_ld] float32 (the env's rows: state_dim proprioceptive floats, then the first
+ * VO row of in_dim floats); weights float32 as nn.GRU / nn.LayerNorm store them (w_ih [3 hidden][in_dim], b_ih / b_hh
+ * [3 hidden], gates r, z, n; the *_r pointers NULL for a unidirectional GRU; ln_w / ln_b [state_dim + hidden]).
+ * feat [rows][feat_ld] of feat_dtype RVO3D_F32 / RVO3D_BF16 receives the state_dim + hidden features (columns beyond
+ * stay untouched: the caller's zero padding for the next GEMM).  hidden 64 / 128 / 192 / 256, in_dim 9, state_dim <= 32.
+ * Rows whose vo_count exceeds 1 need the full recurrence: the caller recomputes those afterwards. */
+typedef struct rvo3d_gru_reader {
+  const float *w_ih_f, *b_ih_f, *b_hh_f;
+  const float *w_ih_r, *b_ih_r, *b_hh_r;
+  const float *ln_w, *ln_b;
+  int32_t hidden, in_dim, state_dim;
+  float ln_eps;
+} rvo3d_gru_reader;
+int rvo3d_reader_first_step(const rvo3d_gru_reader *reader, const float *obs, int64_t obs_ld, int64_t rows,
+                            void *feat, int32_t feat_dtype, int64_t feat_ld, void *stream);
+
 /* The bookkeeping behind `env.drone_step` in the rollout loop (multi_ppo.py:217-281), for E envs x N drones
  * (N <= 512): the reward into its buffer slot (inf / nan as 0 when sanitize), episode return / length
  * counters, which paths end behind this step (cut_slot [E]: any drone of the env finished or timed out,

@@ -162,7 +162,48 @@ def test_rollout_account_matches_the_module_path(E, N):
         assert bool(anyx.item()) == bool(want[4].any())
 
 
-@pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (False, "rnn"), (False, "mlp_small")])
+@pytest.mark.parametrize("hidden,bi,dt", [(256, True, torch.float32), (256, True, torch.bfloat16), (128, False, torch.float32),
+                                          (64, True, torch.float32), (192, True, torch.bfloat16)])
+def test_reader_first_step_matches_the_module(hidden, bi, dt):
+    """rvo3d_reader_first_step against rnn_Reader.forward_batch (policy_rnn_ac.py:75-127) on rows with one VO row:
+    float32 statement of the same GRU cell / sum / concat / LayerNorm; tolerance 3e-5 absolute (fast exp / rcp in
+    the kernel's sigmoid and tanh; features are O(1) after the LayerNorm), bf16 output: one bf16 ulp on top."""
+    from rvo3d_amd.policy.policy_rnn_ac import rnn_Reader
+    torch.manual_seed(hidden)
+    rows, W = 4099, 102   # ragged: not a multiple of the eight rows per trip
+    r = rnn_Reader(12, 9, hidden, use_gpu=False, mode="biGRU" if bi else "GRU").cuda()
+    with torch.no_grad():   # away from the default init so that every term matters
+        for p_ in r.parameters():
+            p_.add_(torch.randn_like(p_) * 0.3)
+    obs = torch.randn((rows, W), device=DEV)
+    obs[:, 21:] = 0.0
+    obs[::7, 12:21] = 0.0   # drones without any VO row: the reference's single all-zero row
+    with torch.no_grad():
+        want = r.forward_batch(obs, torch.ones(rows, dtype=torch.int64, device=DEV))
+    D = 12 + hidden
+    ld = (D + 63) // 64 * 64
+    feat = torch.full((rows, ld), 7.0, dtype=dt, device=DEV)
+    g = r.rnn_net
+    f = lambda t: t.detach().float().contiguous()
+    w = [f(g.weight_ih_l0), f(g.bias_ih_l0), f(g.bias_hh_l0)] + \
+        ([f(g.weight_ih_l0_reverse), f(g.bias_ih_l0_reverse), f(g.bias_hh_l0_reverse)] if bi else [None] * 3) + \
+        [f(r.ln.weight), f(r.ln.bias)]
+    st = _lib.GruReader(*[None if t is None else t.data_ptr() for t in w], hidden, 9, 12, float(r.ln.eps))
+    L = _lib.lib()
+    _lib.check(L.rvo3d_reader_first_step(C.byref(st), _p(obs), W, rows, _p(feat),
+                                         _lib.RVO3D_BF16 if dt == torch.bfloat16 else _lib.RVO3D_F32, ld,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rvo3d_reader_first_step")
+    torch.cuda.synchronize()
+    got = feat[:, :D].float()
+    tol = 3e-5 if dt == torch.float32 else 3e-5 + 2 ** -8 * float(want.abs().max())
+    assert float((got - want).abs().max()) < tol, float((got - want).abs().max())
+    assert bool((feat[:, D:] == 7.0).all())   # the caller's padding is not touched
+    bad = _lib.GruReader(*[None if t is None else t.data_ptr() for t in w], 100, 9, 12, 1e-5)
+    assert L.rvo3d_reader_first_step(C.byref(bad), _p(obs), W, rows, _p(feat), 0, ld, None) == -1
+
+
+@pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (False, "rnn"), (False, "mlp_small"),
+                                      (False, "rnn256"), (True, "rnn256")])
 def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     """The fused loop (multi_ppo._collect_fused) on 16 drones x 64 envs: (a) a second env stepped with the
     STORED actions reproduces every stored observation, count and reward bit for bit - the buffer holds
@@ -173,17 +214,20 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     world = synthetic_world(E, N, (20, 20, 8), n_points=3, seed=4)
     env = BatchedDroneEnv(world)
     torch.manual_seed(0)
-    if kind == "rnn":   # the reference's architecture (biGRU reader): its own forward, then the "direct" kernel mode
+    if kind.startswith("rnn"):
+        # the reference's architecture (biGRU reader).  "rnn": widths without a kernel instantiation - its own forward,
+        # then the "direct" mode; "rnn256": the trained shape (256 / (256, 256)) - reader kernel + heads kernel
         from rvo3d_amd.policy import rnn_ac
 
         class Space:
             shape = (3,)
-        ac = rnn_ac(None, Space(), 12, 9, 32, (64, 64), (64, 64), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+        hs, mh = (32, (64, 64)) if kind == "rnn" else (256, (256, 256))
+        ac = rnn_ac(None, Space(), 12, 9, hs, mh, mh, torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
                     use_gpu=False, rnn_mode="biGRU").cuda()
     else:               # (64, 64): a hidden width the heads kernel has no instantiation for -> "direct" as well
         ac = mlp_ac(env.W, hidden_sizes=(64, 64) if kind == "mlp_small" else (256, 256)).cuda()
     tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3)
-    assert tr._fused_mode() == ("heads" if kind == "mlp" else "direct")
+    assert tr._fused_mode() == ("heads" if kind in ("mlp", "rnn256") else "direct")
     env.reset(); env.observe()
     mean_ret = tr.collect()
     buf = tr.buf
@@ -210,7 +254,7 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     # (b) the stored numbers against the module's own float32 forward on the stored observations
     with torch.no_grad():
         x = buf.obs[:T].reshape(-1, env.W)
-        arg = (x, buf.cnt[:T].reshape(-1)) if kind == "rnn" else x
+        arg = (x, buf.cnt[:T].reshape(-1)) if kind.startswith("rnn") else x
         d, _ = ac.pi(arg)
         v = ac.v(arg)
     tol = 3e-2 if amp else 1e-4  # bf16 GEMMs in the rollout vs the float32 module

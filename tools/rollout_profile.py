@@ -14,6 +14,7 @@ ap.add_argument("--envs", type=int, default=4096)
 ap.add_argument("--drones", type=int, default=64)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--fp32", action="store_true")
+ap.add_argument("--policy", default="mlp", help="mlp | rnn (the reference's biGRU actor-critic, 256 hidden)")
 ap.add_argument("--chunk", type=int, default=0, help="rows per policy pass (0: all at once)")
 ap.add_argument("--tunable", action="store_true", help="torch.cuda.tunable: let TunableOp pick the hipBLASLt solution per GEMM shape")
 ap.add_argument("--module-path", action="store_true", help="the unfused loop (PyTorch glue)")
@@ -22,7 +23,15 @@ if args.tunable:
     import torch.cuda.tunable as tun
     tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(2000); tun.set_filename(os.path.join(ROOT, 'gpurun_out', 'tunableop_results.csv'))
 env = BatchedDroneEnv(synthetic_world(args.envs, args.drones, (50, 50, 10)))
-ac = mlp_ac(env.W).cuda()
+if args.policy == "mlp":
+    ac = mlp_ac(env.W).cuda()
+else:
+    from rvo3d_amd.policy import rnn_ac
+
+    class Space:
+        shape = (3,)
+    ac = rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                use_gpu=False, rnn_mode="biGRU").cuda()
 tr = multi_ppo(env, ac, steps_per_epoch=args.steps, max_ep_len=500, amp=not args.fp32,
                fused_rollout=not args.module_path, rollout_chunk=args.chunk)
 env.reset(); env.observe()
