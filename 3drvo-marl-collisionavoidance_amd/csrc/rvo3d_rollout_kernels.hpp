@@ -296,7 +296,8 @@ struct ReaderArgs {
   void* feat; int32_t feat_bf16; int64_t feat_ld;
 };
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// (v_rcp_f32 / v_rsq_f32 directly, 1 ulp: __frcp_rn is the correctly rounded reciprocal, a ten-instruction sequence)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigmoid(2.0f * x) - 1.0f; }
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
   uint32_t u = __builtin_bit_cast(uint32_t, f);
@@ -312,7 +313,7 @@ constexpr int kReaderMaxSd = 32; // state_dim <= 32
 template <int IN>
 __global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs A) {
   __shared__ float s_in[kReaderRows][kReaderMaxSd + kReaderMaxIn];
-  __shared__ float s_red[kReaderRows][4];
+  __shared__ float s_red[kReaderRows][4], s_red2[kReaderRows][4];
   __shared__ float s_stat[2][kReaderRows];  // mean, 1 / sqrt(var + eps) of the eight rows
   __shared__ __attribute__((aligned(16))) uint16_t s_out[kReaderRows][kReaderMaxSd + 256];  // bf16 rows on their way out
   const int u = threadIdx.x, H = A.H, SD = A.SD, D = SD + H;
@@ -374,38 +375,32 @@ __global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs
         // clamped exponents: exp(88) overflows float32 to inf and inf / inf is NaN; beyond +-30 the cell saturates anyway
         const float ez = __expf(-__builtin_fmaxf(__builtin_fminf(rz[dir].y, 30.f), -30.f));
         const float en = __expf(-2.0f * __builtin_fmaxf(__builtin_fminf(a, 15.f), -15.f));
-        const float hd = ez * (1.0f - en) * __frcp_rn((1.0f + ez) * (1.0f + en));
+        const float hd = ez * (1.0f - en) * __builtin_amdgcn_rcpf((1.0f + ez) * (1.0f + en));
         if (dir == 0 || bi) hs += hd;
       }
       h[r] = hs;
     }
-    // LayerNorm (biased variance, eps inside the root: torch.nn.LayerNorm), two passes over the eight rows: wave
-    // sums of the hidden part, then thread r < 8 adds the waves' partial sums and the row's proprioceptive part
+    // LayerNorm (biased variance, eps inside the root: torch.nn.LayerNorm): per row the sum and the sum of squares of
+    // the hidden part (wave reduction, one pass: the features are O(1), 268 of them - var = E[x^2] - mean^2 loses
+    // nothing visible at float32), then thread r < rows adds the waves' partial sums and the row's proprioceptive part
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int r = 0; r < kReaderRows; ++r) {
+      float v = h[r], q = h[r] * h[r];
 #pragma unroll
-      for (int r = 0; r < kReaderRows; ++r) {
-        const float m = pass == 0 ? 0.f : s_stat[0][r];
-        float v = pass == 0 ? h[r] : (h[r] - m) * (h[r] - m);
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh, 64);
-        if (lane == 0) s_red[r][wv] = v;
-      }
-      __syncthreads();
-      if (u < kReaderRows) {
-        float t = 0.f;
-        for (int q = 0; q < nwv; ++q) t += s_red[u][q];
-        if (pass == 0) {
-          for (int k = 0; k < SD; ++k) t += s_in[u][k];
-          s_stat[0][u] = t / (float)D;
-        } else {
-          const float m = s_stat[0][u];
-          for (int k = 0; k < SD; ++k) { const float d = s_in[u][k] - m; t += d * d; }
-          s_stat[1][u] = __frsqrt_rn(t / (float)D + A.eps);
-        }
-      }
-      __syncthreads();
+      for (int sh = 32; sh >= 1; sh >>= 1) { v += __shfl_xor(v, sh, 64); q += __shfl_xor(q, sh, 64); }
+      if (lane == 0) { s_red[r][wv] = v; s_red2[r][wv] = q; }
     }
+    __syncthreads();
+    if (u < kReaderRows) {
+      float t = 0.f, t2 = 0.f;
+      for (int q = 0; q < nwv; ++q) { t += s_red[u][q]; t2 += s_red2[u][q]; }
+      for (int k = 0; k < SD; ++k) { const float x = s_in[u][k]; t += x; t2 += x * x; }
+      const float m = t / (float)D;
+      const float var = __builtin_fmaxf(t2 / (float)D - m * m, 0.f);
+      s_stat[0][u] = m;
+      s_stat[1][u] = __builtin_amdgcn_rsqf(var + A.eps);
+    }
+    __syncthreads();
     if (A.feat_bf16 && (D & 3) == 0) {
       // bf16 rows leave through LDS: a thread storing its own 2 bytes per row makes 128-byte store instructions of
       // byte-masked dwords (the kernel spent half its time there); staged, the trip's eight rows go out as 8-byte
