@@ -588,6 +588,28 @@ def rollout_block(env, args):
                "update_first_call_s": round(t2b - t2, 4),
                "update_samples_per_s": round(E * N * T * 4 / (t3 - t2b), 1)}
         rec.update(tr.rollout_profile())  # env_kernel_us, launches_per_step (None when not measurable)
+        # the reference's own architecture (biGRU reader 9 -> 256, LayerNorm(268), actor / critic 268-256-256;
+        # train/policy/policy_rnn_ac.py:31-257) through the same loop: rollout only, 8 steps
+        try:
+            del tr, data
+            torch.cuda.empty_cache()
+            from rvo3d_amd.policy import rnn_ac
+
+            class _Space:
+                shape = (3,)
+            ac2 = rnn_ac(None, _Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh,
+                         torch.nn.Identity, use_gpu=False, rnn_mode="biGRU").to(dev)
+            tr2 = multi_ppo(env, ac2, train_epoch=0, steps_per_epoch=8, max_ep_len=500, save_freq=10 ** 9, amp=True)
+            env.reset(); env.observe()
+            tr2.collect(); tr2.buf.ptr = 0; tr2.buf.cut.zero_()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            tr2.collect()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            rec["reference_architecture"] = {"policy": "rnn_ac biGRU(9 -> 256) + LayerNorm(268) + MLP(256,256) heads, bf16",
+                                             "path": tr2._fused_mode(), "ms_per_step": round((t1 - t0) / 8 * 1e3, 4),
+                                             "drone_steps_per_s": round(E * N * 8 / (t1 - t0), 1)}
+        except Exception as ex:
+            rec["reference_architecture"] = {"error": f"{type(ex).__name__}: {ex}"}
         return rec
     except Exception as ex:  # the headline must not die with the secondary measurement
         return {"error": f"{type(ex).__name__}: {ex}"}
