@@ -421,3 +421,51 @@ def test_two_rank_update_equals_one_rank_on_the_concatenated_data():
     tr.update({k: torch.cat([d[k] for d in both]) for k in both[0]})
     one = torch.cat([p.detach().reshape(-1) for p in ac.parameters()]).numpy()
     np.testing.assert_allclose(out[0], one, rtol=2e-5, atol=2e-6)
+
+
+def test_fused_plan_reproduces_the_module_forward():
+    """The rollout's inference plan (merged first layers, per-net hidden layers, float32 head rows for
+    rvo3d_policy_sample) against the modules' own forward, float32, on the CPU."""
+    from rvo3d_amd.policy.policy_rnn_ac import _hidden_pair
+    torch.manual_seed(3)
+    ac = mlp_ac(102)
+    plan = ac.fused_plan(torch.float32)
+    assert plan is not None and plan["hidden"] == 256 and plan["tanh"] and plan["k_pad"] == 102
+    x = torch.randn(50, 102)
+    hp, hv = _hidden_pair(x, plan)
+    mu = torch.tanh(hp @ plan["w_pi"].t() + plan["b_pi"])
+    v = hv @ plan["w_v"] + plan["b_v"]
+    with torch.no_grad():
+        assert torch.allclose(mu, ac.dist(x).mean, atol=1e-6) and torch.allclose(v, ac.v(x), atol=1e-6)
+    assert ac.fused_plan(torch.float32) is plan                      # cached ...
+    with torch.no_grad():
+        ac.log_std.add_(0.1)                                         # ... until a parameter changes
+    assert ac.fused_plan(torch.float32) is not plan
+    assert ac.fused_plan(torch.bfloat16)["k_pad"] == 128             # reduced precision: K padded to a multiple of 64
+    assert mlp_ac(21, hidden_sizes=(8, 8)).fused_plan(torch.float32)["hidden"] == 8  # (the trainer checks the width)
+    odd = mlp_ac(21)
+    odd.v_net = torch.nn.Sequential(torch.nn.Linear(21, 256), torch.nn.Tanh(), torch.nn.Linear(256, 1), torch.nn.Identity())
+    assert odd.fused_plan(torch.float32) is None                     # not a ReLU stack of the actor's depth
+
+
+def test_reader_one_step_fast_path_equals_the_masked_recurrence():
+    """rnn_Reader.forward_batch evaluates one GRU cell step from h = 0 for every row and the unrolled masked
+    recurrence only for rows with several VO rows: it must be the same function as the recurrence on all rows."""
+    from rvo3d_amd.policy.policy_rnn_ac import rnn_Reader
+    torch.manual_seed(5)
+    for mode in ("biGRU", "GRU"):
+        r = rnn_Reader(12, 9, 24, use_gpu=False, mode=mode)
+        B, S = 300, 10
+        obs = torch.randn(B, 12 + 9 * S)
+        lens = torch.randint(1, S + 1, (B,))
+        lens[: B // 2] = 1
+        x = obs[:, 12:].reshape(B, S, 9)
+        with torch.no_grad():
+            h = r._gru_dir(x, lens, "", False)
+            if mode == "biGRU":
+                h = h + r._gru_dir(x, lens, "_reverse", True)
+            want = r.ln(torch.cat((obs[:, :12], h), 1))
+            got = r.forward_batch(obs, lens)
+        assert torch.equal(got[: B // 2], want[: B // 2])            # one-step rows: bit for bit
+        assert torch.allclose(got, want, atol=1e-6)
+        assert torch.equal(r.forward_batch(obs[: B // 2], lens[: B // 2]), want[: B // 2])  # a batch without long rows
