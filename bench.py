@@ -343,6 +343,11 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1 or args.force_dist:
+        # The bucket is 0.74 MB: latency-bound, a few channels carry it; every channel is a workgroup that holds wave
+        # slots on a CU while the env launch wants ALL of them for its one round of 4096 waves (measured at one rank:
+        # a collective kernel alongside costs the env step up to 24 %).  RCCL's own choice can be restored by setting
+        # the variable in the environment.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
         if world == 1:
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             os.environ.setdefault("MASTER_PORT", str(_free_port()))
