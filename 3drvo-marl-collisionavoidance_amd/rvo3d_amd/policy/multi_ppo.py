@@ -155,7 +155,7 @@ class multi_ppo:
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
                  dist=None, sanitize_rewards=True, amp=False, reference_order=False, fused_rollout=True,
-                 rollout_chunk=None, tune_gemms=True, **kwargs):
+                 rollout_chunk=None, tune_gemms=True, tune_update=False, **kwargs):
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
         # The agent order of the reference-order update comes from a generator of its own, seeded like
@@ -170,6 +170,10 @@ class multi_ppo:
         # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 3 s per shape) and keeps
         # the fastest - at 64 x 4096 a 256x256x64 stream-K kernel, 70 us, instead of the heuristic's 84 us
         self.tune_gemms = bool(tune_gemms)
+        # the same for the update's GEMMs (a dozen shapes incl. the tall-skinny weight-gradient products): measured
+        # at 64 x 4096, T = 16, fp32: 0.285 -> 0.214 s per (2 + 2)-iteration update, for ~50 s of tuning in the first
+        # update of the process - worth it for a training run, not for a benchmark: opt-in
+        self.tune_update = bool(tune_update)
         # key of the counter-based action noise of the fused rollout (rvo3d_policy_sample): per rank
         self._sample_seed = (int(seed) * 0x9E3779B97F4A7C15 + 0x1234567 * (
             dist.get_rank() if (dist is not None and dist.is_initialized()) else 0)) & 0xFFFFFFFFFFFFFFFF
@@ -548,6 +552,15 @@ class multi_ppo:
         """multi_ppo.update (multi_ppo.py:341-376).  `data`: the flattened rollout of
         RolloutBuffer.get(), or - the reference's own signature - a list with one buffer dict
         per agent (obs = ragged list or padded `obs` + `cnt`)."""
+        if self.tune_update and self.device.type == "cuda" and not getattr(self, "_in_tuned_update", False):
+            self._in_tuned_update = True
+            try:
+                keep, self.tune_gemms = self.tune_gemms, True
+                with self._tuned_gemms():
+                    return self.update(data)
+            finally:
+                self.tune_gemms = keep
+                self._in_tuned_update = False
         if isinstance(data, (list, tuple)):
             return self._update_reference_order(list(data))
         if self.reference_order:
