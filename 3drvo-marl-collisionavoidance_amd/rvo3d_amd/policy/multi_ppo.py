@@ -344,7 +344,6 @@ class multi_ppo:
             env.step_policy(buf.act[t], autoreset=True, obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
             since_full_reset += 1
             epoch_ended = final_reset and t == T - 1
-            ac["any_extra"].zero_()
             _lib.check(L.rvo3d_rollout_account(E, N, p(env.reward), p(env.done), p(env.finish),
                                                1 if self.sanitize_rewards else 0, int(self.max_ep_len),
                                                1 if epoch_ended else 0, p(buf.rew[t]), p(self.ep_ret), p(self.ep_len),
@@ -353,9 +352,13 @@ class multi_ppo:
             buf.ptr += 1
             # only now can an episode have timed out (no episode is longer than the steps since the last
             # full reset): before that the device is not asked (no synchronisation in the loop)
+            # (any_extra is sticky: the kernel only ever sets it, and it is cleared here once its drones are
+            # handled - one launch per step less than clearing it before every step; a timeout cannot occur, and
+            # the flag cannot be set, before since_full_reset exceeds max_ep_len or the epoch ends)
             if epoch_ended or (since_full_reset > self.max_ep_len and int(ac["any_extra"].item()) != 0):
                 env.reset_drones(ac["extra"])
                 env.observe(obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
+                ac["any_extra"].zero_()
         buf.cut[:T] |= ac["cut"].bool()
         self._cur = (buf.obs[T], buf.cnt[T])
         s = ac["sums"].sum(dim=0).tolist()
