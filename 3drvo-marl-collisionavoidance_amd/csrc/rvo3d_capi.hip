@@ -215,6 +215,27 @@ bool allow_lds_all(int bytes) {
 
 }  // namespace
 
+#ifndef RVO3D_MLP_WAVES
+#define RVO3D_MLP_WAVES 8
+#endif
+namespace {
+constexpr int kMlpWaves = RVO3D_MLP_WAVES;  // waves per workgroup of policy_mlp_kernel
+template <int KS1>
+int launch_policy_mlp(const rvo3d::PolicyMlpArgs& A, unsigned grid, hipStream_t s) {
+  constexpr int tps = KS1 <= 7 ? 2 : 1;
+  constexpr int lds = rvo3d::kMlpResidentBytes + 2 * tps * KS1 * 1024;
+  static bool attr_set = false;  // (per process and instantiation; the attribute is per device function)
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rvo3d::policy_mlp_kernel<KS1, kMlpWaves>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rvo3d::policy_mlp_kernel<KS1, kMlpWaves>), dim3(grid), dim3(64 * kMlpWaves), lds, s, A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int rvo3d_version(void) { return RVO3D_VERSION; }
@@ -649,6 +670,74 @@ int rvo3d_policy_sample(const rvo3d_policy_heads* hd, int64_t rows, float std_fa
   }
   HIP_TRY(hipGetLastError());
   return RVO3D_OK;
+  RVO3D_API_END
+}
+
+int64_t rvo3d_policy_mlp_blob_bytes(int32_t obs_width) {
+  if (obs_width < 1 || obs_width > 126) return -1;
+  return 2 * rvo3d::mlp_net_bytes(rvo3d::mlp_ks1(obs_width));
+}
+
+int rvo3d_policy_mlp_pack(const rvo3d_mlp_weights* pi, const rvo3d_mlp_weights* v, int32_t obs_width, void* blob,
+                          void* stream) {
+  RVO3D_API_BEGIN
+  if (!pi || !v || !blob) return fail(RVO3D_ERR_INVALID, "null pointer");
+  if (obs_width < 1 || obs_width > 126) return fail(RVO3D_ERR_INVALID, "obs_width must be 1..126");
+  if (reinterpret_cast<uintptr_t>(blob) & 15) return fail(RVO3D_ERR_INVALID, "blob must be 16-byte aligned");
+  const rvo3d_mlp_weights* n[2] = {pi, v};
+  rvo3d::MlpPackArgs A;
+  A.k_in = obs_width; A.ks1 = rvo3d::mlp_ks1(obs_width);
+  for (int i = 0; i < 2; ++i) {
+    if (!n[i]->w1 || !n[i]->b1 || !n[i]->w2 || !n[i]->b2 || !n[i]->w3 || !n[i]->b3)
+      return fail(RVO3D_ERR_INVALID, "null weight pointer");
+    A.w1[i] = n[i]->w1; A.b1[i] = n[i]->b1; A.w2[i] = n[i]->w2; A.b2[i] = n[i]->b2; A.w3[i] = n[i]->w3; A.b3[i] = n[i]->b3;
+  }
+  A.blob = static_cast<unsigned char*>(blob);
+  hipLaunchKernelGGL(rvo3d::mlp_pack_kernel, dim3(64, 2), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
+int rvo3d_policy_mlp_sample(const void* blob, int32_t obs_width, const float* obs, int64_t obs_ld, int64_t rows,
+                            int32_t tanh_out, const float* log_std, float std_factor, uint64_t seed, uint64_t step,
+                            float* act, float* logp, float* val, float* dbg_mu, float* dbg_raw, void* stream) {
+  RVO3D_API_BEGIN
+  if (!blob || !obs || !log_std || !act || !logp || !val) return fail(RVO3D_ERR_INVALID, "null pointer");
+  if (obs_width < 1 || obs_width > 126) return fail(RVO3D_ERR_INVALID, "obs_width must be 1..126");
+  if (rows < 0 || obs_ld < obs_width) return fail(RVO3D_ERR_INVALID, "rows < 0 or obs_ld < obs_width");
+  if (rows > 0 && ((rows - 1) * obs_ld + obs_width) * 4 > (int64_t)0x7fffffff)
+    return fail(RVO3D_ERR_INVALID, "the observation array must stay below 2 GiB per call (32-bit buffer offsets): split the rows");
+  if (reinterpret_cast<uintptr_t>(obs) & 3) return fail(RVO3D_ERR_INVALID, "obs must be 4-byte aligned");
+  if (reinterpret_cast<uintptr_t>(blob) & 15) return fail(RVO3D_ERR_INVALID, "blob must be 16-byte aligned");
+  if (rows == 0) return RVO3D_OK;
+  int dev = 0, cus = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int ks1 = rvo3d::mlp_ks1(obs_width);
+  rvo3d::PolicyMlpArgs A;
+  A.blob = static_cast<const unsigned char*>(blob); A.net_bytes = rvo3d::mlp_net_bytes(ks1);
+  A.obs = obs; A.ld_obs = obs_ld; A.k_in = obs_width;
+  A.S = rvo3d::PolicySampleArgs{};
+  A.S.tanh_out = tanh_out; A.S.log_std = log_std; A.S.std_factor = std_factor; A.S.seed = seed; A.S.step = step;
+  A.S.rows = rows; A.S.act = act; A.S.logp = logp; A.S.val = val; A.S.dbg_mu = dbg_mu; A.S.dbg_raw = dbg_raw;
+  // one workgroup per CU, half of them per network; every wave takes 64 rows per trip
+  const int64_t nchunks = (rows + 63) / 64;
+  int64_t G = (nchunks + kMlpWaves - 1) / kMlpWaves;
+  const int64_t Gmax = cus >= 2 ? cus / 2 : 1;
+  if (G > Gmax) G = Gmax;
+  const unsigned grid = (unsigned)(2 * G);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (ks1) {
+    case 1: return launch_policy_mlp<1>(A, grid, s);
+    case 2: return launch_policy_mlp<2>(A, grid, s);
+    case 3: return launch_policy_mlp<3>(A, grid, s);
+    case 4: return launch_policy_mlp<4>(A, grid, s);
+    case 5: return launch_policy_mlp<5>(A, grid, s);
+    case 6: return launch_policy_mlp<6>(A, grid, s);
+    case 7: return launch_policy_mlp<7>(A, grid, s);
+    default: return launch_policy_mlp<8>(A, grid, s);
+  }
   RVO3D_API_END
 }
 

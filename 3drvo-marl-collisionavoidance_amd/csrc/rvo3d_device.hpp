@@ -29,7 +29,8 @@
 // Files: rvo3d_params.hpp (parameter blocks), rvo3d_math.hpp (arithmetic model, per-drone
 // pieces), rvo3d_lds.hpp (LDS views), rvo3d_pairs.hpp (pair pipeline), rvo3d_step.hpp (the step
 // kernel), rvo3d_aux_kernels.hpp (resets, tables, classical RVO selection), rvo3d_rollout_kernels.hpp (the
-// trainer's per-step glue: policy heads + sampling, episode bookkeeping).
+// trainer's per-step glue: policy heads + sampling, episode bookkeeping), rvo3d_policy_mlp.hpp (config 3's MLP(256, 256)
+// policy step on the matrix cores).
 #pragma once
 
 #include "rvo3d_params.hpp"
@@ -39,3 +40,4 @@
 #include "rvo3d_step.hpp"
 #include "rvo3d_aux_kernels.hpp"
 #include "rvo3d_rollout_kernels.hpp"
+#include "rvo3d_policy_mlp.hpp"

@@ -432,6 +432,9 @@ enum Mode { kObserve = 0, kStep = 1, kStepAutoReset = 2 };
 #ifndef RVO3D_STAGGER_ZEROS
 #define RVO3D_STAGGER_ZEROS 0
 #endif
+#ifndef RVO3D_DEPHASE
+#define RVO3D_DEPHASE 0
+#endif
 
 // 128 VGPRs = 4 waves per SIMD.  One-wave workgroups (N <= 64): the 4096 waves of 64 x 4096 are
 // all resident at once.  N <= 256 (one env per workgroup of 2 or 4 waves): the fourth wave per
@@ -492,10 +495,27 @@ __global__ void __launch_bounds__(64 * NW) RVO3D_WAVES_ATTR env_kernel(const Par
   // one resident round move through the phases together - everybody loads, everybody computes, everybody
   // stores - and the memory system idles while they compute; with the two halves out of step the stores
   // of one half fill the load / compute phases of the other.
-  const bool zeros_first = LITE && ((blockIdx.x >> 3) & 1) && two_phase_rows(P, row0, nrows, full_rows);
+#if RVO3D_STAGGER_ZEROS == 2
+  // by the wave's slot on its SIMD (HW_ID bits 3:0), so that the waves sharing one SIMD are out of step
+  unsigned hw_id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+  const bool odd_half = NW == 1 ? (hw_id & 1) : ((blockIdx.x >> 3) & 1);
+#else
+  const bool odd_half = (blockIdx.x >> 3) & 1;
+#endif
+  const bool zeros_first = LITE && odd_half && two_phase_rows(P, row0, nrows, full_rows);
   if (zeros_first) early_zero_blocks<NW>(P, L, tid, row0, nrows);
 #else
   const bool zeros_first = false;
+#endif
+#if RVO3D_DEPHASE
+  // (experiment, off) waves in odd slots of their SIMD start RVO3D_DEPHASE x ~0.94 us (2048 cycles) late
+  if (NW == 1) {
+    unsigned hw_slot;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_slot));
+    if (hw_slot & 1)
+      for (int i = 0; i < RVO3D_DEPHASE; ++i) __builtin_amdgcn_s_sleep(32);
+  }
 #endif
   Drone S;
   S.x = S.y = S.z = S.vx = S.vy = S.vz = 0.0; S.r = 0.2; S.prio = 5;

@@ -155,7 +155,7 @@ class multi_ppo:
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
                  dist=None, sanitize_rewards=True, amp=False, reference_order=False, fused_rollout=True,
-                 rollout_chunk=None, tune_gemms=True, tune_update=False, **kwargs):
+                 rollout_chunk=None, tune_gemms=True, tune_update=False, fused_mlp=True, **kwargs):
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
         # The agent order of the reference-order update comes from a generator of its own, seeded like
@@ -165,6 +165,9 @@ class multi_ppo:
         # shards: rank r samples from torch's generator seeded seed + r (rank 0 = the reference's seed).
         self._order_rng = np.random.RandomState(seed)
         self.fused_rollout = bool(fused_rollout)
+        # bf16 rollouts of the MLP(256, 256) actor-critic: the policy step as ONE matrix-core kernel
+        # (rvo3d_policy_mlp_sample) instead of cast + three library GEMMs + rvo3d_policy_sample
+        self.fused_mlp = bool(fused_mlp)
         self.rollout_chunk = rollout_chunk  # rows per policy pass of the fused rollout (None / 0: all at once)
         # the rollout's policy GEMMs ([E*N, 128] x [128, 512], [E*N, 256] x [256, 256], bf16) through PyTorch's
         # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 3 s per shape) and keeps
@@ -218,12 +221,16 @@ class multi_ppo:
 
     # ---- rollout ------------------------------------------------------------------------
     def _fused_mode(self):
-        """How a rollout step runs on the GPU: "heads" - the MLP actor-critic, everything from the last hidden
-        layers on in rvo3d_policy_sample; "direct" - any other actor-critic with the reference's surface
+        """How a rollout step runs on the GPU: "mlp" - config 3's MLP(256, 256) actor-critic in reduced precision:
+        the whole policy step (cast, hidden layers, heads, sampling, stores) is ONE kernel on the matrix cores,
+        rvo3d_policy_mlp_sample; "heads" - other MLP actor-critics (and float32): library GEMMs up to the last
+        hidden layers, everything from there on in rvo3d_policy_sample; "direct" - any other actor-critic with the reference's surface
         (`ac.pi._distribution`, `ac.v`, e.g. the biGRU rnn_ac): its own forward gives mu and v, the kernel
         samples / rounds / stores; None - the module path of collect() (CPU, or fused_rollout=False)."""
         if self.device.type != "cuda" or not self.fused_rollout:
             return None
+        if self.amp and self.fused_mlp and hasattr(self.ac, "mlp_blob") and self.ac.mlp_blob() is not None:
+            return "mlp"
         if hasattr(self.ac, "fused_plan"):
             plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
             if plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024)):
@@ -307,6 +314,13 @@ class multi_ppo:
         for t in range(T):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
+            if mode == "mlp":
+                mb = self.ac.mlp_blob()
+                _lib.check(L.rvo3d_policy_mlp_sample(p(mb["blob"]), env.W, p(x), x.stride(0), E * N,
+                                                     1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
+                                                     ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
+                           "rvo3d_policy_mlp_sample")
+                ac["step"] += 1
             if mode == "direct":
                 mu, v = self._mu_v(x, buf.cnt[t].view(E * N))
                 hd = _lib.PolicyHeads(mu.data_ptr(), v.data_ptr(), mu.stride(0), 1, _lib.RVO3D_F32, 0, 0, 0,

@@ -441,6 +441,42 @@ class mlp_ac(nn.Module):
         the module path)."""
         return _plan_cached(self, dtype, lambda: _mlp_pair_plan(self.pi_net, self.v_net, dtype))
 
+    def mlp_blob(self):
+        """The packed weights of rvo3d_policy_mlp_sample (the whole policy step in ONE kernel on the matrix cores:
+        csrc/rvo3d_policy_mlp.hpp), repacked when a parameter changed; None when this is not the shape that kernel
+        is written for - ReLU MLPs obs_width -> 256 -> 256 -> 3 (Tanh or Identity) / -> 1, obs_width <= 126, on a GPU."""
+        pl = [m for m in self.pi_net if isinstance(m, nn.Linear)]
+        vl = [m for m in self.v_net if isinstance(m, nn.Linear)]
+        pa = [m for m in self.pi_net if not isinstance(m, nn.Linear)]
+        va = [m for m in self.v_net if not isinstance(m, nn.Linear)]
+        if (len(pl) != 3 or len(vl) != 3 or self.obs_width > 126 or pl[0].weight.device.type != "cuda"
+                or [m.out_features for m in pl] != [256, 256, 3] or [m.out_features for m in vl] != [256, 256, 1]
+                or not all(isinstance(m, nn.ReLU) for m in pa[:-1] + va[:-1]) or len(pa) != 3 or len(va) != 3
+                or not isinstance(pa[-1], (nn.Tanh, nn.Identity)) or not isinstance(va[-1], nn.Identity)
+                or any(m.bias is None for m in pl + vl) or pl[0].weight.dtype != torch.float32):
+            return None
+        params = list(self.pi_net.parameters()) + list(self.v_net.parameters())
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        hit = getattr(self, "_blob", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        import ctypes as C
+        from .. import _lib
+        L = _lib.lib()
+        dev = pl[0].weight.device
+        blob = hit[1]["blob"] if hit is not None else torch.empty(int(L.rvo3d_policy_mlp_blob_bytes(self.obs_width)),
+                                                                   dtype=torch.uint8, device=dev)
+        keep = [t.detach().contiguous() for lin in (pl, vl) for m in lin for t in (m.weight, m.bias)]
+        a = _lib.MlpWeights(*[t.data_ptr() for t in keep[:6]])
+        b = _lib.MlpWeights(*[t.data_ptr() for t in keep[6:]])
+        with torch.cuda.device(dev):
+            _lib.check(L.rvo3d_policy_mlp_pack(C.byref(a), C.byref(b), self.obs_width, C.c_void_p(blob.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "rvo3d_policy_mlp_pack")
+        out = dict(blob=blob, tanh=isinstance(pa[-1], nn.Tanh))
+        self._blob = (key, out)
+        return out
+
     def prepare_input(self, obs, cnt, plan, cache):
         """The A operand of the first-layer GEMM: the observation itself (float32) or - ONE kernel - its cast into a
         zero-padded [rows, Kp] buffer kept in `cache`."""

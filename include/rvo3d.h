@@ -164,6 +164,27 @@ int rvo3d_policy_sample(const rvo3d_policy_heads *heads, int64_t rows, float std
                         uint64_t step, float *act, float *logp, float *val, float *dbg_mu,
                         float *dbg_raw, void *stream);
 
+/* Config 3's policy step - MLP(256, 256) actor and critic (train/policy/policy_rnn_ac.py:197-257 with the hidden sizes
+ * of BASELINE config 3; ac.step, :57-69) - as ONE kernel over the env's observation rows: cast, both hidden layers and
+ * the heads on the matrix cores with the activations kept in registers (bf16 operands, float32 accumulation), then what
+ * rvo3d_policy_sample does per row (tanh, sample, log-probability, np.round(a, 2), the stores).  Replaces, per rollout
+ * step, the observation cast, three GEMMs and rvo3d_policy_sample.
+ * rvo3d_policy_mlp_pack turns the nn.Linear tensors (float32, weight [out][in], as the modules store them; widths
+ * obs_width -> 256 -> 256 -> 3 for the actor, -> 1 for the critic) into the device blob the kernel reads
+ * (rvo3d_policy_mlp_blob_bytes(obs_width) bytes, 16-byte aligned; repack after every optimizer step).
+ * obs [rows][obs_ld] float32, obs_width <= 126.  Noise as rvo3d_policy_sample: Philox4x32-10, counter (row, step). */
+typedef struct rvo3d_mlp_weights {
+  const float *w1, *b1; /* [256][obs_width], [256] */
+  const float *w2, *b2; /* [256][256], [256] */
+  const float *w3, *b3; /* [3][256], [3] (actor) or [1][256], [1] (critic) */
+} rvo3d_mlp_weights;
+int64_t rvo3d_policy_mlp_blob_bytes(int32_t obs_width);
+int rvo3d_policy_mlp_pack(const rvo3d_mlp_weights *pi, const rvo3d_mlp_weights *v, int32_t obs_width, void *blob,
+                          void *stream);
+int rvo3d_policy_mlp_sample(const void *blob, int32_t obs_width, const float *obs, int64_t obs_ld, int64_t rows,
+                            int32_t tanh_out, const float *log_std, float std_factor, uint64_t seed, uint64_t step,
+                            float *act, float *logp, float *val, float *dbg_mu, float *dbg_raw, void *stream);
+
 /* rnn_Reader.obs_rnn (train/policy/policy_rnn_ac.py:75-127) for observations with AT MOST ONE velocity-obstacle row
  * - nearly all of a rollout's -: the (bi)GRU over a one-step sequence from h = 0 (one cell evaluation per direction,
  * no recurrent product), the sum of the two directions, the concatenation with the proprioceptive part and the

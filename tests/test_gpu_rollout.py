@@ -83,6 +83,158 @@ def test_policy_sample_matches_torch(dt, hidden, rows):
     assert not torch.equal(raw, raw4)
 
 
+def _mlp_pack(ac, W):
+    L = _lib.lib()
+    blob = torch.zeros(int(L.rvo3d_policy_mlp_blob_bytes(W)), dtype=torch.uint8, device=DEV)
+    keep = [t.detach().float().contiguous() for net in (ac.pi_net, ac.v_net) for m in net
+            if isinstance(m, torch.nn.Linear) for t in (m.weight, m.bias)]
+    a, b = _lib.MlpWeights(*[t.data_ptr() for t in keep[:6]]), _lib.MlpWeights(*[t.data_ptr() for t in keep[6:]])
+    _lib.check(L.rvo3d_policy_mlp_pack(C.byref(a), C.byref(b), W, _p(blob), None), "rvo3d_policy_mlp_pack")
+    torch.cuda.synchronize()
+    return blob
+
+
+def _mlp_sample(blob, W, x, log_std, tanh=True, seed=7, step=0, std_factor=1.0, rows=None):
+    L = _lib.lib()
+    rows = x.shape[0] if rows is None else rows
+    act = torch.full((rows, 3), 9.0, device=DEV)
+    logp = torch.full((rows,), 9.0, device=DEV)
+    val = torch.full((rows,), 9.0, device=DEV)
+    mu = torch.zeros((rows, 3), device=DEV)
+    raw = torch.zeros((rows, 3), device=DEV)
+    _lib.check(L.rvo3d_policy_mlp_sample(_p(blob), W, _p(x), x.stride(0), rows, 1 if tanh else 0, _p(log_std), std_factor,
+                                         seed, step, _p(act), _p(logp), _p(val), _p(mu), _p(raw),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rvo3d_policy_mlp_sample")
+    torch.cuda.synchronize()
+    return act, logp, val, mu, raw
+
+
+def _mlp_emulation(ac, x):
+    """The kernel's arithmetic in plain PyTorch: bf16 operands (observation, weights, the first layer's bias, both
+    hidden activations), float32 products / sums / second bias / head bias."""
+    bf = torch.bfloat16
+
+    def net(n):
+        lin = [m for m in n if isinstance(m, torch.nn.Linear)]
+        h = x.to(bf).double()
+        h = torch.relu(h @ lin[0].weight.to(bf).double().T + lin[0].bias.to(bf).double()).float().to(bf).double()
+        h = torch.relu(h @ lin[1].weight.to(bf).double().T + lin[1].bias.double()).float().to(bf).double()
+        return (h @ lin[2].weight.to(bf).double().T + lin[2].bias.double()).float()
+    with torch.no_grad():
+        return net(ac.pi_net), net(ac.v_net).squeeze(-1)
+
+
+def test_policy_mlp_layouts_with_exact_integer_data():
+    """Every fragment layout of the kernel (A / B operand maps, the permuted k order of a chained product, the
+    bias table, the head rows, the two-pass row ownership) with small-integer weights and inputs: every product and
+    sum is exact in bf16 x bf16 -> float32, so the result must EQUAL the integer arithmetic - a swapped row, lane
+    or k index cannot hide behind a tolerance."""
+    W, rows = 102, 64 * 37 + 5
+    g = torch.Generator(device=DEV).manual_seed(5)
+    ac = mlp_ac(W).to(DEV)
+    with torch.no_grad():
+        for net in (ac.pi_net, ac.v_net):
+            lin = [m for m in net if isinstance(m, torch.nn.Linear)]
+            lin[0].weight.copy_(torch.randint(-2, 3, lin[0].weight.shape, device=DEV, generator=g).float())
+            lin[0].bias.copy_(torch.randint(-3, 4, lin[0].bias.shape, device=DEV, generator=g).float())
+            # sparse second layer and head: the sums stay below 2^8 (exact in bf16 after the ReLU) / 2^24
+            w2 = torch.randint(-1, 2, lin[1].weight.shape, device=DEV, generator=g).float()
+            w2 *= (torch.rand(w2.shape, device=DEV, generator=g) < 0.04).float()
+            lin[1].weight.copy_(w2)
+            lin[1].bias.copy_(torch.randint(-2, 3, lin[1].bias.shape, device=DEV, generator=g).float())
+            lin[2].weight.copy_(torch.randint(-2, 3, lin[2].weight.shape, device=DEV, generator=g).float())
+            lin[2].bias.copy_(torch.randint(-5, 6, lin[2].bias.shape, device=DEV, generator=g).float())
+    x = torch.randint(-1, 2, (rows, W), device=DEV, generator=g).float()
+    x *= (torch.rand(x.shape, device=DEV, generator=g) < 0.15).float()
+    with torch.no_grad():
+        h1p, h1v = torch.relu(ac.pi_net[0](x)), torch.relu(ac.v_net[0](x))
+        assert float(h1p.max()) <= 256 and float(h1v.max()) <= 256 and float(h1p.max()) > 8   # exact in bf16
+        h2p, h2v = torch.relu(ac.pi_net[2](h1p)), torch.relu(ac.v_net[2](h1v))
+        assert float(h2p.max()) <= 256 and float(h2v.max()) <= 256 and float(h2p.max()) > 4
+        mu_want, v_want = ac.pi_net[4](h2p), ac.v_net[4](h2v).squeeze(-1)
+    log_std = torch.tensor([-1.0, -0.5, -1.5], device=DEV)
+    act, logp, val, mu, raw = _mlp_sample(_mlp_pack(ac, W), W, x, log_std, tanh=False)
+    assert torch.equal(mu, mu_want), int((mu != mu_want).sum())
+    assert torch.equal(val, v_want), int((val != v_want).sum())
+    assert len(torch.unique(mu_want)) > 30 and len(torch.unique(v_want)) > 30
+
+
+@pytest.mark.parametrize("W,rows", [(102, 262144), (102, 1000), (57, 5000), (39, 777), (120, 4096), (12, 130), (126, 64)])
+def test_policy_mlp_sample_matches_torch(W, rows):
+    """rvo3d_policy_mlp_sample against (a) a PyTorch emulation with the kernel's rounding points - the two differ by
+    the summation order inside a product (float32) and by the bf16 roundings of hidden activations that such a
+    difference flips (one bf16 ulp = 2^-8 of one activation): mean 1e-4, max 3e-2 on the pre-activations at these
+    weights; (b) the float32 module: the price of bf16 operands, stated; (c) the sampling lines exactly as
+    test_policy_sample_matches_torch does for rvo3d_policy_sample (same per-row code in the kernel)."""
+    torch.manual_seed(W * 1000 + rows)
+    ac = mlp_ac(W).to(DEV)
+    x = torch.randn((rows + 3, W + 5), device=DEV)[:rows, :W] * 2     # a strided view: obs_ld > obs_width
+    x[::7, 12:] = 0.0                                                 # rows without VO rows, as the env writes them
+    log_std = torch.tensor([-1.0, -0.5, -1.5], device=DEV)
+    blob = _mlp_pack(ac, W)
+    act, logp, val, mu, raw = _mlp_sample(blob, W, x, log_std)
+    z_emu, v_emu = _mlp_emulation(ac, x)
+    mu_emu = torch.tanh(z_emu)
+    d_mu, d_v = (mu - mu_emu).abs(), (val - v_emu).abs()
+    assert float(d_mu.max()) < 1e-2 and float(d_mu.mean()) < 2e-4, (float(d_mu.max()), float(d_mu.mean()))
+    assert float(d_v.max()) < 1e-2 and float(d_v.mean()) < 2e-4, (float(d_v.max()), float(d_v.mean()))
+    with torch.no_grad():
+        mu32, v32 = ac.pi_net(x), ac.v_net(x).squeeze(-1)
+    assert float((mu - mu32).abs().max()) < 3e-2 and float((val - v32).abs().max()) < 3e-2
+    std = torch.clamp(torch.exp(log_std) + 1e-6, 1e-4, 10.0)
+    lp_ref = torch.distributions.Normal(mu, std).log_prob(raw).sum(-1)
+    assert torch.allclose(logp, lp_ref, atol=1e-4, rtol=1e-5), float((logp - lp_ref).abs().max())
+    assert np.array_equal(act.cpu().numpy(), np.round(raw.cpu().numpy(), 2))
+    eps = ((raw - mu) / std).cpu().numpy()
+    assert np.isfinite(eps).all()
+    if rows >= 4096:
+        n = eps.size
+        assert abs(eps.mean()) < 4 / math.sqrt(n) and abs(eps.var() - 1) < 6 * math.sqrt(2 / n)
+    # same key and counter: the same noise as rvo3d_policy_sample draws for the row (one generator for all paths)
+    zero = torch.zeros((rows, 3), device=DEV)
+    _, _, _, _, raw_d = _sample(zero, torch.zeros((rows, 1), device=DEV), None, None, None, None, log_std, rows, 0,
+                                _lib.RVO3D_F32)
+    assert torch.allclose(raw - mu, raw_d, atol=1e-6, rtol=0)
+    # reproducible; another step / seed: other numbers; a repack after a weight change is seen
+    _, logp2, val2, _, raw2 = _mlp_sample(blob, W, x, log_std)
+    assert torch.equal(raw, raw2) and torch.equal(logp, logp2) and torch.equal(val, val2)
+    assert not torch.equal(raw, _mlp_sample(blob, W, x, log_std, step=1)[4])
+    assert not torch.equal(raw, _mlp_sample(blob, W, x, log_std, seed=8)[4])
+    with torch.no_grad():
+        ac.v_net[4].bias += 1.0
+    assert torch.allclose(_mlp_sample(_mlp_pack(ac, W), W, x, log_std)[2], val + 1.0, atol=1e-5)
+
+
+def test_policy_mlp_sample_reads_only_the_callers_bytes_and_rejects_bad_arguments():
+    """The 16-wide k-steps run past the last row's end: the kernel reads through a buffer descriptor of exactly
+    (rows - 1) ld + width floats.  Here the observation array ends flush with its allocation and is followed by NaNs in
+    a second check - neither may change a result."""
+    L = _lib.lib()
+    W, rows = 102, 200
+    ac = mlp_ac(W).to(DEV)
+    blob = _mlp_pack(ac, W)
+    log_std = torch.zeros(3, device=DEV)
+    big = torch.full((rows * W + 64,), float("nan"), device=DEV)
+    x = big[:rows * W].view(rows, W)
+    x.copy_(torch.randn((rows, W), device=DEV))
+    a = _mlp_sample(blob, W, x, log_std)
+    b = _mlp_sample(blob, W, x.clone(), log_std)
+    assert all(torch.equal(p, q) for p, q in zip(a, b)) and bool(torch.isfinite(a[3]).all())
+    # a prefix of the rows gives the prefix of the results (ragged last 64-row group)
+    c = _mlp_sample(blob, W, x, log_std, rows=77)
+    assert torch.equal(c[3], a[3][:77]) and torch.equal(c[2], a[2][:77])
+    v = torch.zeros(8, device=DEV)
+    args = lambda **k: [k.get("blob", _p(blob)), k.get("W", W), _p(x), k.get("ld", W), k.get("rows", rows), 1, _p(log_std),
+                        1.0, 0, 0, _p(v), _p(v), _p(v), None, None, None]
+    assert L.rvo3d_policy_mlp_sample(*args(W=127)) == -1 and b"obs_width" in L.rvo3d_last_error()
+    assert L.rvo3d_policy_mlp_sample(*args(ld=W - 1)) == -1
+    assert L.rvo3d_policy_mlp_sample(*args(blob=None)) == -1
+    assert L.rvo3d_policy_mlp_sample(*args(rows=-1)) == -1
+    assert L.rvo3d_policy_mlp_sample(*args(blob=C.c_void_p(blob.data_ptr() + 4))) == -1
+    assert L.rvo3d_policy_mlp_sample(*args(rows=0)) == 0
+    assert L.rvo3d_policy_mlp_blob_bytes(0) == -1 and L.rvo3d_policy_mlp_blob_bytes(102) == 2 * (7 * 8192 + 131072 + 1024 + 2048 + 16)
+
+
 def test_policy_sample_direct_mode_and_std_factor():
     """hidden = 0: mu / v come from the caller's own network (the biGRU actor-critic); std_factor as the
     evaluator uses it (post_train.py: std_factor 1e-3 -> std clamps at 1e-4 + ...)."""
@@ -202,7 +354,7 @@ def test_reader_first_step_matches_the_module(hidden, bi, dt):
     assert L.rvo3d_reader_first_step(C.byref(bad), _p(obs), W, rows, _p(feat), 0, ld, None) == -1
 
 
-@pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (False, "rnn"), (False, "mlp_small"),
+@pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (True, "mlp_gemm"), (False, "rnn"), (False, "mlp_small"),
                                       (False, "rnn256"), (True, "rnn256")])
 def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     """The fused loop (multi_ppo._collect_fused) on 16 drones x 64 envs: (a) a second env stepped with the
@@ -226,8 +378,12 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
                     use_gpu=False, rnn_mode="biGRU").cuda()
     else:               # (64, 64): a hidden width the heads kernel has no instantiation for -> "direct" as well
         ac = mlp_ac(env.W, hidden_sizes=(64, 64) if kind == "mlp_small" else (256, 256)).cuda()
-    tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3)
-    assert tr._fused_mode() == ("heads" if kind in ("mlp", "rnn256") else "direct")
+    # bf16 + MLP(256, 256): the whole policy step is rvo3d_policy_mlp_sample ("mlp"); "mlp_gemm" keeps the library-GEMM
+    # path of the same shape alive (other widths / float32 use it)
+    tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3,
+                   fused_mlp=kind != "mlp_gemm")
+    assert tr._fused_mode() == ("mlp" if (kind == "mlp" and amp) else "heads" if kind in ("mlp", "mlp_gemm", "rnn256")
+                                else "direct")
     env.reset(); env.observe()
     mean_ret = tr.collect()
     buf = tr.buf
