@@ -222,8 +222,7 @@ namespace {
 constexpr int kMlpWaves = RVO3D_MLP_WAVES;  // waves per workgroup of policy_mlp_kernel
 template <int KS1>
 int launch_policy_mlp(const rvo3d::PolicyMlpArgs& A, unsigned grid, hipStream_t s) {
-  constexpr int tps = KS1 <= 7 ? 2 : 1;
-  constexpr int lds = rvo3d::kMlpResidentBytes + 2 * tps * KS1 * 1024;
+  constexpr int lds = rvo3d::mlp_lds_bytes(KS1);
   static bool attr_set = false;  // (per process and instantiation; the attribute is per device function)
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rvo3d::policy_mlp_kernel<KS1, kMlpWaves>),

@@ -13,12 +13,16 @@
 // the packed weights of the following layer are stored in that order).  A wave takes 32 batch rows at a time through all layers (28 + 64 registers of bf16
 // activations, 16 + 16 of accumulators) and finishes 64 rows - two passes - at once, one row per lane.
 //
-// Weights.  One workgroup (8 waves, one per CU: 2 per SIMD) serves ONE of the two networks and keeps its second layer
-// (128 KB of packed bf16 fragments, 1 KB per wave-load, lane-linear: conflict-free ds_read_b128) in LDS for its whole
-// life; the first layer (8 tiles of KS1 KB) is streamed through a double-buffered 2-tile LDS stage that the workgroup
-// fills in lockstep (global_load_lds: no registers; one barrier per stage, the next stage in flight behind the MFMAs).  The first
-// layer's bias rides in the weight column k_in against a constant 1 in the activations; the second layer's bias is the
-// C operand of the first MFMA of a tile; the heads are a third chained product (3 or 1 of 32 rows used).
+// Weights.  One workgroup (8 waves, one per CU: 2 per SIMD) serves ONE of the two networks and keeps in LDS, for its
+// whole life, that network's first layer (8 KS1 KB of packed bf16 fragments, 1 KB per wave-load, lane-linear:
+// conflict-free ds_read_b128), the second layer's bias table, the head rows and 12 of the 16 k-steps of every
+// second-layer tile (96 KB); the other four k-steps per tile (32 KB per pass) every wave streams from L2 into registers
+// one tile ahead.  After the one barrier behind that copy the waves run free.  The first layer's bias rides in the
+// weight column k_in against a constant 1 in the activations; the second layer's bias is the C operand of the first
+// MFMA of a tile; the heads are a third chained product (3 or 1 of 32 rows used).
+// (An earlier version kept the whole second layer in LDS and streamed the first through a double-buffered LDS stage
+// with a workgroup barrier per stage: the barriers kept the two waves of a SIMD in step - MFMA phases together,
+// conversion / waits / sampling together - and the matrix pipe was busy 48 % of the time.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -112,60 +116,83 @@ struct PolicyMlpArgs {
 };
 
 __device__ __forceinline__ float relu_f32(float x) {
-  // one instruction (fmaxf would canonicalise first); a builtin, not inline asm: the compiler pads the MFMA -> VALU
-  // read hazard for its own instructions only
-  return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
+  // ONE instruction beside the MFMAs (v_max_i32: as integers, negative floats are negative, positive ones keep their
+  // order).  fmaxf / fmed3 cost two - the compiler canonicalises the operand first -, and inline asm is out: the
+  // compiler pads the MFMA -> VALU read hazard for its own instructions only.
+  const int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
 }
 #ifndef RVO3D_MLP_ABL
-#define RVO3D_MLP_ABL 0  // (timing experiments only: 1 no sampling, 2 no stage barriers, 8 no row prefetch)
+#define RVO3D_MLP_ABL 0  // (timing experiments only: 1 no sampling, 8 no observation loads)
 #endif
+#ifndef RVO3D_MLP_XPREFETCH
+#define RVO3D_MLP_XPREFETCH 0  // 1: the next pass's rows are requested behind the last tile of layer 2
+#endif
+#ifndef RVO3D_MLP_CLOCK
+#define RVO3D_MLP_CLOCK 0
+#endif
+// second-layer k-steps per tile whose fragments stay in LDS; the other 16 - TR are streamed from L2 per wave
+__host__ __device__ constexpr int mlp_tr(int ks1) { return ks1 <= 7 ? 12 : 11; }
+__host__ __device__ constexpr int mlp_lds_bytes(int ks1) {
+  return 8 * ks1 * 1024 + kMlpB2Bytes + kMlpW3Bytes + 8 * mlp_tr(ks1) * 1024;
+}
+
 template <int KS1, int NW>
 __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs A) {
-  constexpr int TPS = KS1 <= 7 ? 2 : 1;                 // first-layer tiles per LDS stage
-  constexpr int SPC = 8 / TPS;                          // stages per pass (even)
-  constexpr int kStageBytes = TPS * KS1 * 1024;
-  constexpr int kWaveLoads = TPS * KS1;                 // 1 KB pieces (one wave-wide 16-byte load each) of a stage
-  static_assert(kMlpResidentBytes + 2 * kStageBytes <= 160 * 1024, "LDS");
+  constexpr int TR = mlp_tr(KS1), NS = 16 - TR;
+  static_assert(mlp_lds_bytes(KS1) <= 160 * 1024, "LDS");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const w2s = smem;
-  const float* const b2t = reinterpret_cast<const float*>(smem + kMlpW2Bytes);
-  const unsigned char* const w3s = smem + kMlpW2Bytes + kMlpB2Bytes;
-  unsigned char* const stage = smem + kMlpResidentBytes;
+  // LDS: the whole first layer, the second layer's bias table, the head rows, TR of 16 k-steps of every second-layer tile
+  const unsigned char* const w1s = smem;
+  const float* const b2t = reinterpret_cast<const float*>(smem + 8 * KS1 * 1024);
+  const unsigned char* const w3s = smem + 8 * KS1 * 1024 + kMlpB2Bytes;
+  const unsigned char* const w2r = w3s + kMlpW3Bytes;
 
+#if RVO3D_MLP_CLOCK
+  const uint64_t clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the staging loops are scalar loops)
-  const int net = blockIdx.x & 1, g = blockIdx.x >> 1, G = gridDim.x >> 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // the actor's and the critic's workgroup of one group of rows on the SAME XCD (workgroup b runs on XCD b % 8): they
+  // read the same observation rows at about the same time, the second reader finds them in that XCD's L2
+  const bool paired = (gridDim.x & 15) == 0;
+  const int net = paired ? (blockIdx.x >> 3) & 1 : blockIdx.x & 1;
+  const int g = paired ? (blockIdx.x >> 4) * 8 + (blockIdx.x & 7) : blockIdx.x >> 1, G = gridDim.x >> 1;
   const unsigned char* const blob = A.blob + net * A.net_bytes;
+  const unsigned char* const gw2 = blob + (int64_t)8 * KS1 * 1024;  // [8][16] blocks of 1 KB
   const int64_t rows = A.S.rows;
   const int64_t nchunks = (rows + 63) >> 6;
   const int iters = (int)((nchunks + (int64_t)G * NW - 1) / ((int64_t)G * NW));
 
-  // resident part: second layer, its bias, the head
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(blob + (int64_t)8 * KS1 * 1024);
+  {  // the resident weights: the only workgroup-wide step of the kernel
     uint4* dst = reinterpret_cast<uint4*>(smem);
-    for (int i = tid; i < kMlpResidentBytes / 16; i += 64 * NW) dst[i] = src[i];
+    const uint4* src = reinterpret_cast<const uint4*>(blob);
+    for (int i = tid; i < 8 * KS1 * 64; i += 64 * NW) dst[i] = src[i];
+    dst += 8 * KS1 * 64;
+    src = reinterpret_cast<const uint4*>(gw2 + kMlpW2Bytes);
+    for (int i = tid; i < (kMlpB2Bytes + kMlpW3Bytes) / 16; i += 64 * NW) dst[i] = src[i];
+    dst += (kMlpB2Bytes + kMlpW3Bytes) / 16;
+    src = reinterpret_cast<const uint4*>(gw2);
+    for (int i = tid; i < 8 * TR * 64; i += 64 * NW) {
+      const int blk = i >> 6, m2 = blk / TR, t = blk - m2 * TR;
+      dst[i] = src[(m2 * 16 + t) * 64 + (i & 63)];
+    }
   }
-  // first-layer stage sc -> buffer b, global -> LDS without registers (lane-linear on both sides)
-  auto dma_stage = [&](int sc, int b) {
-    for (int i = wave; i < kWaveLoads; i += NW)
-      __builtin_amdgcn_global_load_lds(
-          (const void __attribute__((address_space(1)))*)(blob + ((int64_t)(sc * kWaveLoads + i) * 64 + lane) * 16),
-          (void __attribute__((address_space(3)))*)(stage + b * kStageBytes + i * 1024), 16, 0, 0);
-  };
-  dma_stage(0, 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
-
+  // From here on the waves run free: no barrier, nothing shared is written.  (Measured and left out: starting the second
+  // half of the waves half a pass late, 110 vs 107 us; s_setprio 1 for the younger half - the half that gets the SIMD's
+  // issue slots finishes after 68 us, the other after 90-100 us, whichever it is: 104 us either way.)
   const float4 head_bias = *reinterpret_cast<const float4*>(blob + A.net_bytes - kMlpHeadBiasBytes);
+  const SampleConsts SC = sample_consts(A.S);
 
   // The observation rows are read through a buffer descriptor over exactly the bytes the caller owns: the 16-wide
   // k-steps run past a row's end (into the next row: masked below) and, for the last row, past the array's end,
   // where the hardware's range check returns zeros instead of touching memory.
   const __amdgpu_buffer_rsrc_t obs_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A.obs), 0, (int)(uint32_t)(((rows - 1) * A.ld_obs + A.k_in) * 4), 0x00020000);
-  f32x8 Xraw[KS1];  // the NEXT pass's 32 rows, requested while the current pass is in its second layer
+  f32x8 Xraw[KS1];
   auto request_rows = [&](int pass) {
+#if !(RVO3D_MLP_ABL & 8)
     const int64_t c = (int64_t)g * NW + wave + (int64_t)(pass >> 1) * G * NW;
     int64_t row = c * 64 + 32 * (pass & 1) + r;
     if (row >= rows) row = rows - 1;  // (a ragged tail / an idle wave re-reads the last row; nothing is stored)
@@ -176,12 +203,41 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
       const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(obs_rs, off + 64 * s + 16, 0, 0));
       Xraw[s] = f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     }
+#endif
   };
+#if RVO3D_MLP_XPREFETCH
   request_rows(0);
+#endif
+
+  // Both layers are written as explicit software pipelines, one `sched_barrier` per MFMA: the A fragment of step
+  // i + D is requested before the MFMA of step i, and the previous tile's epilogue (ReLU, conversion to the next
+  // product's B fragments: 24 VALU instructions) is spread over the current tile's MFMAs, in whose shadow it runs -
+  // two accumulators alternate.  (Left alone the scheduler sinks every LDS read to just before its MFMA and the
+  // optimiser defers all epilogues of a layer to its end, with every accumulator live.)
+  // epilogue step q = 0..7 of a finished tile: registers 2 q, 2 q + 1 -> ReLU -> one packed bf16 pair
+  auto epi = [&](const f32x16& acc, int q) -> uint32_t {
+    uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(
+                                                  f32x2{relu_f32(acc[2 * q]), relu_f32(acc[2 * q + 1])}, bf16x2));
+    asm volatile("" : "+v"(w));  // (pinned to this slot of the pipeline)
+    return w;
+  };
+  auto stream_frag = [&](int m2, int u) {  // k-step TR + u of second-layer tile m2, from L2
+    return *reinterpret_cast<const bf16x8*>(gw2 + ((int64_t)((m2 * 16 + TR + u) * 64 + lane)) * 16);
+  };
 
   float zs0 = 0.f, zs1 = 0.f, zs2 = 0.f;
+#if RVO3D_MLP_CLOCK
+  uint64_t tk[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define RVO3D_MLP_STAMP(i) { const uint64_t tn = __builtin_amdgcn_s_memtime(); tk[i] += tn - tprev; tprev = tn; }
+#else
+#define RVO3D_MLP_STAMP(i)
+#endif
 #pragma unroll 1
   for (int pass = 0; pass < 2 * iters; ++pass) {
+    RVO3D_MLP_STAMP(3)
+#if !RVO3D_MLP_XPREFETCH
+    request_rows(pass);
+#endif
     // ---- 32 observation rows as the B fragments of the first product (cast to bf16 on the way) ----
     bf16x8 X[KS1];
 #pragma unroll
@@ -196,35 +252,29 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
       }
       X[s] = __builtin_convertvector(v, bf16x8);
     }
-    // Both layers are written as explicit software pipelines, one `sched_barrier` per MFMA: the A fragment of step
-    // i + D is requested before the MFMA of step i, and the previous tile's epilogue (ReLU, conversion to the next
-    // product's B fragments: 24 VALU instructions) is spread over the current tile's MFMAs, in whose shadow it runs -
-    // two accumulators alternate.  (Left alone the scheduler sinks every LDS read to just before its MFMA and the
-    // optimiser defers all epilogues of a layer to its end, with every accumulator live.)
+    asm volatile("" :: "v"(X[0]), "v"(X[KS1 - 1]));
+    RVO3D_MLP_STAMP(0)
     u32x4 H1[16];  // H1^T [256][32] as the 16 B fragments of the second product
     f32x16 accs[2];
-    // epilogue step q = 0..7 of a finished tile: registers 2 q, 2 q + 1 -> ReLU -> one packed bf16 pair
-    auto epi = [&](const f32x16& acc, int q) -> uint32_t {
-      uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(
-                                                    f32x2{relu_f32(acc[2 * q]), relu_f32(acc[2 * q + 1])}, bf16x2));
-      asm volatile("" : "+v"(w));  // (pinned to this slot of the pipeline)
-      return w;
-    };
-    // ---- layer 1: H1^T = relu(W1 X^T), tile by tile out of the stage buffers ----
-#pragma unroll
-    for (int sc = 0; sc < SPC; ++sc) {
-      // the next stage lands in the other buffer (everybody finished reading it one barrier ago) meanwhile
-      dma_stage((sc + 1) % SPC, (sc + 1) & 1);
-      const unsigned char* const sb = stage + (sc & 1) * kStageBytes;
-      constexpr int D1 = 4, kSteps = TPS * KS1;
+    bf16x8 S[NS];  // the streamed fragments of the next second-layer tile
+    // ---- layer 1: H1^T = relu(W1 X^T): one flat stream of 8 KS1 fragments out of LDS ----
+    {
+      constexpr int D1 = 4, kSteps = 8 * KS1;
+      const unsigned char* const wb = w1s + lane * 16;
       bf16x8 ring[D1];
 #pragma unroll
-      for (int i = 0; i < D1 && i < kSteps; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(sb + (i * 64 + lane) * 16);
+      for (int i = 0; i < D1; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
 #pragma unroll
-      for (int i = 0; i < kSteps; ++i) {
-        const int ml = i / KS1, s2 = i % KS1, m = sc * TPS + ml;
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int s2 = 0; s2 < KS1; ++s2) {
+        const int i = m * KS1 + s2;
         const bf16x8 a = ring[i % D1];
-        if (i + D1 < kSteps) ring[i % D1] = *reinterpret_cast<const bf16x8*>(sb + ((i + D1) * 64 + lane) * 16);
+        if (i + D1 < kSteps) ring[i % D1] = *reinterpret_cast<const bf16x8*>(wb + (i + D1) * 1024);
+        if (i == kSteps - KS1) {
+#pragma unroll
+          for (int u = 0; u < NS; ++u) S[u] = stream_frag(0, u);
+        }
         if (s2 == 0) {
           const f32x16 z = {0};
           accs[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, X[s2], z, 0, 0, 0);
@@ -238,14 +288,12 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-#if !(RVO3D_MLP_ABL & 2)
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the next stage has landed
-      __syncthreads();
-#endif
+      // (the last tile's epilogue is not overlapped: the second layer's first MFMAs - the streamed k-steps 12..15 -
+      // need it at once)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) H1[14 + (q >> 2)][q & 3] = epi(accs[1], q);
     }
-#if !(RVO3D_MLP_ABL & 8)
-    if (pass + 1 < 2 * iters) request_rows(pass + 1);
-#endif
+    RVO3D_MLP_STAMP(1)
     // ---- layer 2 + heads: H2^T = relu(W2 H1^T + b2), head^T += W3 H2^T ----
     f32x16 hd = {0};
     {
@@ -260,8 +308,9 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
         }
         return b;
       };
-      // one flat stream of 128 A fragments (8 tiles x 16 k-steps, consecutive in LDS), D2 of them in flight
-      const unsigned char* const wb = w2s + lane * 16;
+      // per tile: first the NS streamed k-steps (their registers are then free for the next tile's request, which has
+      // the TR resident steps to land), then the TR resident ones - one flat stream of 8 TR fragments in LDS, D2 in flight
+      const unsigned char* const wb = w2r + lane * 16;
       bf16x8 ring[D2];
 #pragma unroll
       for (int i = 0; i < D2; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
@@ -273,28 +322,40 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
 #pragma unroll
       for (int m2 = 0; m2 < 8; ++m2) {
         f32x16& cur = accs[m2 & 1];
-        const f32x16& prev = accs[(m2 & 1) ^ 1];  // layer 1's last tile when m2 == 0 (7 is odd)
+        const f32x16& prev = accs[(m2 & 1) ^ 1];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          const int i = m2 * 16 + t;
-          const bf16x8 a = ring[i % D2];
-          if (i + D2 < 128) ring[i % D2] = *reinterpret_cast<const bf16x8*>(wb + (i + D2) * 1024);
-          cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, H1[t]), t == 0 ? bias : cur, 0, 0, 0);
-          if (t >= 1 && t <= 8) {  // the previous tile's epilogue, one packed pair per step
-            const int q = t - 1;
-            if (m2 == 0) H1[14 + (q >> 2)][q & 3] = epi(prev, q);
-            else h2[q >> 2][q & 3] = epi(prev, q);
+        for (int v = 0; v < 16; ++v) {
+          bf16x8 a;
+          int t;  // the k-step this MFMA covers
+          if (v < NS) {
+            a = S[v]; t = TR + v;
+          } else {
+            const int i = m2 * TR + (v - NS);
+            a = ring[i % D2]; t = v - NS;
+            if (i + D2 < 8 * TR) ring[i % D2] = *reinterpret_cast<const bf16x8*>(wb + (i + D2) * 1024);
           }
-          if (m2 > 0 && t == 6) {
+          cur = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, H1[t]), v == 0 ? bias : cur, 0, 0, 0);
+          if (v == NS - 1 && m2 < 7) {
+#pragma unroll
+            for (int u = 0; u < NS; ++u) S[u] = stream_frag(m2 + 1, u);
+          }
+          if (m2 > 0 && v >= 1 && v <= 8) {  // the previous tile's epilogue, one packed pair per step
+            const int q = v - 1;
+            h2[q >> 2][q & 3] = epi(prev, q);
+          }
+          if (m2 > 0 && v == 6) {
             a3[0] = *reinterpret_cast<const bf16x8*>(w3l + (2 * (m2 - 1)) * 128);
             a3[1] = *reinterpret_cast<const bf16x8*>(w3l + (2 * (m2 - 1) + 1) * 128);
           }
-          if (t == 8 && m2 < 7) bias = read_bias(m2 + 1);
-          if (m2 > 0 && t == 10) hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], __builtin_bit_cast(bf16x8, h2[0]), hd, 0, 0, 0);
-          if (m2 > 0 && t == 12) hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], __builtin_bit_cast(bf16x8, h2[1]), hd, 0, 0, 0);
+          if (v == 8 && m2 < 7) bias = read_bias(m2 + 1);
+          if (m2 > 0 && v == 10) hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], __builtin_bit_cast(bf16x8, h2[0]), hd, 0, 0, 0);
+          if (m2 > 0 && v == 12) hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], __builtin_bit_cast(bf16x8, h2[1]), hd, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#if RVO3D_MLP_XPREFETCH
+      if (pass + 1 < 2 * iters) request_rows(pass + 1);
+#endif
       // the last tile's epilogue and head products
       a3[0] = *reinterpret_cast<const bf16x8*>(w3l + 14 * 128);
       a3[1] = *reinterpret_cast<const bf16x8*>(w3l + 15 * 128);
@@ -303,6 +364,8 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
       hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], __builtin_bit_cast(bf16x8, h2[0]), hd, 0, 0, 0);
       hd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], __builtin_bit_cast(bf16x8, h2[1]), hd, 0, 0, 0);
     }
+    asm volatile("" :: "v"(hd));
+    RVO3D_MLP_STAMP(2)
     // ---- rows 0..2 of a head tile sit in registers 0..2 of lanes 0..31: the lower half keeps the first pass's and
     // finishes those 32 rows after the second pass, when the upper half takes the second pass's ----
     if ((pass & 1) == 0) {
@@ -317,11 +380,26 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
 #if RVO3D_MLP_ABL & 1
       if (net == 0) A.S.logp[row] = z0 + z1 + z2;
 #else
-      if (net == 0) finish_row(A.S, row, z0, z1, z2);
+      if (net == 0) finish_row(A.S, SC, row, z0, z1, z2);
 #endif
       else A.S.val[row] = z0;
     }
   }
+#if RVO3D_MLP_CLOCK  // (experiment: shader cycles and 100 MHz ticks of one wave's life)
+  if (tid == 0 && net == 1 && g == 0) {
+    A.S.act[0] = (float)(__builtin_amdgcn_s_memtime() - clk0);
+    A.S.act[1] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);
+  }
+  if (lane == 0 && A.S.dbg_mu) {  // per wave: start / end in 100 MHz ticks (low 24 bits), XCC id
+    float* o = A.S.dbg_mu + 4 * (blockIdx.x * NW + wave);
+    o[0] = (float)(rt0 & 0xFFFFFF); o[1] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFF);
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    o[2] = (float)(xcc & 15); o[3] = (float)((hw >> 8) & 0xff);  // cu_id[11:8] + sh/se bits
+    float* o2 = A.S.dbg_mu + 4 * (gridDim.x * NW) + 4 * (blockIdx.x * NW + wave);
+    o2[0] = (float)tk[0]; o2[1] = (float)tk[1]; o2[2] = (float)tk[2]; o2[3] = (float)tk[3];
+  }
+#endif
 }
 
 }  // namespace rvo3d

@@ -62,26 +62,44 @@ struct PolicySampleArgs {
   float* dbg_raw;        // optional [rows][3]: the unrounded sample
 };
 
-__device__ __forceinline__ void finish_row(const PolicySampleArgs& A, int64_t row, float z0, float z1, float z2) {
-  // GaussianActor._distribution (policy_rnn_ac.py:217-222): std = clamp(std_factor * exp(log_std) + 1e-6, 1e-4, 10);
+// GaussianActor._distribution (policy_rnn_ac.py:217-222): std = clamp(std_factor * exp(log_std) + 1e-6, 1e-4, 10) - the
+// same for every row of a launch: computed once per lane, not once per row
+struct SampleConsts { float sd[3], inv2var[3], log_sd[3]; };
+__device__ __forceinline__ SampleConsts sample_consts(const PolicySampleArgs& A) {
+  SampleConsts C;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float sd = A.std_factor * __expf(A.log_std[k]) + 1e-6f;
+    sd = sd < 1e-4f ? 1e-4f : (sd > 10.0f ? 10.0f : sd);
+    C.sd[k] = sd; C.inv2var[k] = 1.0f / (2.0f * sd * sd); C.log_sd[k] = __logf(sd);
+  }
+  return C;
+}
+// tanh from one exp and one reciprocal: 1 - 2 / (e^2x + 1); exact limits at both ends, absolute error < 3e-7
+__device__ __forceinline__ float tanh_fast(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f);
+}
+__device__ __forceinline__ void finish_row(const PolicySampleArgs& A, const SampleConsts& C, int64_t row, float z0,
+                                           float z1, float z2) {
   // a ~ Normal(mu, std); logp = sum_k log N(a_k; mu_k, std_k)
   float mu[3] = {z0, z1, z2};
-  if (A.tanh_out) { mu[0] = tanhf(z0); mu[1] = tanhf(z1); mu[2] = tanhf(z2); }
+  if (A.tanh_out) { mu[0] = tanh_fast(z0); mu[1] = tanh_fast(z1); mu[2] = tanh_fast(z2); }
   float eps[3];
   normal3(A.seed, A.step, (uint64_t)row, eps);
   float lp = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    float sd = A.std_factor * __expf(A.log_std[k]) + 1e-6f;
-    sd = sd < 1e-4f ? 1e-4f : (sd > 10.0f ? 10.0f : sd);
-    const float a = mu[k] + sd * eps[k];
+    const float a = mu[k] + C.sd[k] * eps[k];
     const float d = a - mu[k];
-    lp += -(d * d) / (2.0f * sd * sd) - __logf(sd) - 0.9189385332046727f;
+    lp += -(d * d) * C.inv2var[k] - C.log_sd[k] - 0.9189385332046727f;
     A.act[row * 3 + k] = __builtin_rintf(a * 100.0f) / 100.0f;  // np.round(float32, 2): rint(a * 100) / 100
     if (A.dbg_mu) A.dbg_mu[row * 3 + k] = mu[k];
     if (A.dbg_raw) A.dbg_raw[row * 3 + k] = a;
   }
   A.logp[row] = lp;
+}
+__device__ __forceinline__ void finish_row(const PolicySampleArgs& A, int64_t row, float z0, float z1, float z2) {
+  finish_row(A, sample_consts(A), row, z0, z1, z2);
 }
 
 // hidden == 0: mu and v come from the caller's own network (e.g. the biGRU actor-critic); one lane per row.

@@ -583,10 +583,13 @@ def rollout_block(env, args):
         torch.cuda.synchronize(); t2b = time.perf_counter()
         tr.update(data)
         torch.cuda.synchronize(); t3 = time.perf_counter()
-        rec = {"workload": f"{N} drones x {E} envs, MLP(256,256) actor-critic, bf16 policy GEMMs, T = {T} steps; "
+        rec = {"workload": f"{N} drones x {E} envs, MLP(256,256) actor-critic, bf16 policy products, T = {T} steps; "
                            "update = 2 policy + 2 value iterations, minibatch E*N",
-               "path": ("fused (rvo3d_policy_sample + rvo3d_step_policy + rvo3d_rollout_account per step)"
-                        if tr._fused_ok() else "module (PyTorch glue)"),
+               "path": {"mlp": "fused: rvo3d_policy_mlp_sample (the whole policy step, one MFMA kernel) + "
+                               "rvo3d_step_policy + rvo3d_rollout_account per step",
+                        "heads": "fused: library GEMMs + rvo3d_policy_sample + rvo3d_step_policy + rvo3d_rollout_account per step",
+                        "direct": "fused: the module's forward + rvo3d_policy_sample (direct) + rvo3d_step_policy + "
+                                  "rvo3d_rollout_account per step"}.get(tr._fused_mode(), "module (PyTorch glue)"),
                "drone_steps_per_s": round(E * N * T / (t1 - t0), 1),
                "ms_per_step": round((t1 - t0) / T * 1e3, 4),
                "gae_ms": round((t2 - t1) * 1e3, 3), "update_s": round(t3 - t2b, 4),
