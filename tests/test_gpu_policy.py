@@ -83,3 +83,30 @@ def test_reference_order_update_on_device(case):
     for k, v in tr.ac.state_dict().items():
         assert v.is_cuda
         np.testing.assert_allclose(v.cpu().numpy(), fx[f"w{case}:" + k], rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_split_weight_gradient_equals_nn_linear():
+    """policy_rnn_ac._Linear: on large GPU batches the weight gradient is a batch of partial products + a sum;
+    forward identical, gradients equal to nn.Linear's up to the order of the float32 sums (<= 2e-5 of the largest entry);
+    small batches and inference take nn.Linear's own path (bitwise equal)."""
+    from rvo3d_amd.policy.policy_rnn_ac import _Linear, mlp
+    torch.manual_seed(3)
+    net = mlp([102, 256, 256, 3], torch.nn.ReLU, torch.nn.Tanh).cuda()
+    assert all(isinstance(m, torch.nn.Linear) for m in net if hasattr(m, "weight"))
+    ref = torch.nn.Sequential(*[torch.nn.Linear(m.in_features, m.out_features) if isinstance(m, _Linear) else type(m)()
+                                for m in net]).cuda()
+    ref.load_state_dict(net.state_dict())                       # same keys: the reference's checkpoints load
+    for rows in (65536, 1000):
+        x = torch.randn(rows, 102, device="cuda")
+        tgt = torch.randn(rows, 3, device="cuda")
+        for m in (net, ref):
+            m.zero_grad()
+            ((m(x) - tgt) ** 2).mean().backward()
+        with torch.no_grad():
+            assert torch.equal(net(x), ref(x))
+        for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+            scale = float(p2.grad.abs().max())
+            if rows < _Linear.split_rows:
+                assert torch.equal(p1.grad, p2.grad), n1
+            else:
+                assert float((p1.grad - p2.grad).abs().max()) <= 2e-5 * scale, (n1, float((p1.grad - p2.grad).abs().max()), scale)
