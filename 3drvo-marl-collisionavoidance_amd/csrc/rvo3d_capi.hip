@@ -699,7 +699,7 @@ int rvo3d_policy_mlp_pack(const rvo3d_mlp_weights* pi, const rvo3d_mlp_weights* 
 }
 
 int rvo3d_policy_mlp_sample(const void* blob, int32_t obs_width, const float* obs, int64_t obs_ld, int64_t rows,
-                            int32_t tanh_out, const float* log_std, float std_factor, uint64_t seed, uint64_t step,
+                            const int32_t* vo_count, int32_t state_dim, int32_t row_dim, int32_t tanh_out, const float* log_std, float std_factor, uint64_t seed, uint64_t step,
                             float* act, float* logp, float* val, float* dbg_mu, float* dbg_raw, void* stream) {
   RVO3D_API_BEGIN
   if (!blob || !obs || !log_std || !act || !logp || !val) return fail(RVO3D_ERR_INVALID, "null pointer");
@@ -717,6 +717,9 @@ int rvo3d_policy_mlp_sample(const void* blob, int32_t obs_width, const float* ob
   rvo3d::PolicyMlpArgs A;
   A.blob = static_cast<const unsigned char*>(blob); A.net_bytes = rvo3d::mlp_net_bytes(ks1);
   A.obs = obs; A.ld_obs = obs_ld; A.k_in = obs_width;
+  A.cnt = vo_count; A.state_dim = state_dim; A.row_dim = row_dim;
+  if (vo_count && (state_dim < 0 || row_dim < 1 || state_dim > obs_width))
+    return fail(RVO3D_ERR_INVALID, "vo_count needs 0 <= state_dim <= obs_width and row_dim >= 1");
   A.S = rvo3d::PolicySampleArgs{};
   A.S.tanh_out = tanh_out; A.S.log_std = log_std; A.S.std_factor = std_factor; A.S.seed = seed; A.S.step = step;
   A.S.rows = rows; A.S.act = act; A.S.logp = logp; A.S.val = val; A.S.dbg_mu = dbg_mu; A.S.dbg_raw = dbg_raw;

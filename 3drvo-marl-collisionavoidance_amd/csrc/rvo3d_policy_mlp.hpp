@@ -28,6 +28,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "rvo3d_rollout_kernels.hpp"
 
 namespace rvo3d {
@@ -112,6 +114,8 @@ struct PolicyMlpArgs {
   const float* obs;           // [rows][ld_obs] float32: the env's observation rows
   int64_t ld_obs;
   int32_t k_in;               // observation width (12 + 9 nm)
+  const int32_t* cnt;         // optional [rows]: the env's vo_count - a row holds state_dim + row_dim * max(cnt, 1) floats, zeros behind
+  int32_t state_dim, row_dim; // 12, 9
   PolicySampleArgs S;         // tanh_out, log_std, std_factor, seed, step, rows, act / logp / val, dbg_*
 };
 
@@ -191,7 +195,25 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
   const __amdgpu_buffer_rsrc_t obs_rs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(A.obs), 0, (int)(uint32_t)(((rows - 1) * A.ld_obs + A.k_in) * 4), 0x00020000);
   f32x8 Xraw[KS1];
-  auto request_rows = [&](int pass) {
+  // Sparse rows.  The env writes an observation row as state_dim floats, then row_dim floats per kept velocity-obstacle
+  // row, then zeros (in a rollout nearly every row has none or one: 21 of 102 floats); with the env's vo_count at hand a
+  // wave knows how many leading 16-wide k-steps hold data for ANY of its 32 rows: the others are neither loaded nor
+  // multiplied (a zero activation adds exactly nothing to a float32 sum; the last k-step always runs - it carries the
+  // bias column).  n_data = KS1: no counts given, everything is loaded.
+  auto data_steps = [&](int pass) -> int {
+    if (!A.cnt) return KS1;
+    const int64_t c = (int64_t)g * NW + wave + (int64_t)(pass >> 1) * G * NW;
+    int64_t row = c * 64 + 32 * (pass & 1) + r;
+    if (row >= rows) row = rows - 1;
+    int cn = A.cnt[row];
+    cn = cn < 1 ? 1 : cn;
+    const int mine = (A.state_dim + A.row_dim * cn + 15) >> 4;
+    int n = 1;
+#pragma unroll
+    for (int q = 1; q < KS1; ++q) n = __builtin_amdgcn_ballot_w64(mine > q) != 0 ? q + 1 : n;
+    return __builtin_amdgcn_readfirstlane(n);
+  };
+  auto request_rows = [&](int pass, int n_data) {
 #if !(RVO3D_MLP_ABL & 8)
     const int64_t c = (int64_t)g * NW + wave + (int64_t)(pass >> 1) * G * NW;
     int64_t row = c * 64 + 32 * (pass & 1) + r;
@@ -199,14 +221,18 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
     const uint32_t off = (uint32_t)((row * A.ld_obs + 8 * h) * 4);
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
-      const float4 lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(obs_rs, off + 64 * s, 0, 0));
-      const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(obs_rs, off + 64 * s + 16, 0, 0));
-      Xraw[s] = f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      if (s < n_data) {
+        const float4 lo = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(obs_rs, off + 64 * s, 0, 0));
+        const float4 hi = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(obs_rs, off + 64 * s + 16, 0, 0));
+        Xraw[s] = f32x8{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      } else {
+        Xraw[s] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      }
     }
 #endif
   };
 #if RVO3D_MLP_XPREFETCH
-  request_rows(0);
+  request_rows(0, KS1);
 #endif
 
   // Both layers are written as explicit software pipelines, one `sched_barrier` per MFMA: the A fragment of step
@@ -236,7 +262,10 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
   for (int pass = 0; pass < 2 * iters; ++pass) {
     RVO3D_MLP_STAMP(3)
 #if !RVO3D_MLP_XPREFETCH
-    request_rows(pass);
+    const int n_data = data_steps(pass);
+    request_rows(pass, n_data);
+#else
+    const int n_data = KS1;
 #endif
     // ---- 32 observation rows as the B fragments of the first product (cast to bf16 on the way) ----
     bf16x8 X[KS1];
@@ -257,33 +286,40 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
     u32x4 H1[16];  // H1^T [256][32] as the 16 B fragments of the second product
     f32x16 accs[2];
     bf16x8 S[NS];  // the streamed fragments of the next second-layer tile
-    // ---- layer 1: H1^T = relu(W1 X^T): one flat stream of 8 KS1 fragments out of LDS ----
-    {
-      constexpr int D1 = 4, kSteps = 8 * KS1;
+    // ---- layer 1: H1^T = relu(W1 X^T): one flat stream of fragments out of LDS ----
+    // Two straight-line versions, chosen per pass (wave-uniform): every k-step, or - rows whose data ends within the
+    // first ND_SPARSE k-steps, i.e. at most two kept VO rows: nearly all of a rollout - those plus the bias step.
+    constexpr int ND_SPARSE = 2;
+    auto layer1 = [&](auto nd_tag) {
+      constexpr int ND = decltype(nd_tag)::value;                  // leading k-steps with data
+      constexpr int NSTEP = ND < KS1 ? ND + 1 : KS1;               // MFMAs per tile: those + the last (bias) step
+      constexpr int D1 = 4, kSteps = 8 * NSTEP;
+      auto k_of = [](int j) constexpr { return j < ND ? j : KS1 - 1; };   // the k-step of a tile's j-th MFMA
       const unsigned char* const wb = w1s + lane * 16;
+      auto frag = [&](int i) { return *reinterpret_cast<const bf16x8*>(wb + ((i / NSTEP) * KS1 + k_of(i % NSTEP)) * 1024); };
       bf16x8 ring[D1];
 #pragma unroll
-      for (int i = 0; i < D1; ++i) ring[i] = *reinterpret_cast<const bf16x8*>(wb + i * 1024);
+      for (int i = 0; i < D1; ++i) ring[i] = frag(i);
 #pragma unroll
       for (int m = 0; m < 8; ++m)
 #pragma unroll
-      for (int s2 = 0; s2 < KS1; ++s2) {
-        const int i = m * KS1 + s2;
+      for (int j = 0; j < NSTEP; ++j) {
+        const int i = m * NSTEP + j, s2 = k_of(j);
         const bf16x8 a = ring[i % D1];
-        if (i + D1 < kSteps) ring[i % D1] = *reinterpret_cast<const bf16x8*>(wb + (i + D1) * 1024);
-        if (i == kSteps - KS1) {
+        if (i + D1 < kSteps) ring[i % D1] = frag(i + D1);
+        if (i == kSteps - NSTEP) {
 #pragma unroll
           for (int u = 0; u < NS; ++u) S[u] = stream_frag(0, u);
         }
-        if (s2 == 0) {
+        if (j == 0) {
           const f32x16 z = {0};
           accs[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, X[s2], z, 0, 0, 0);
         } else {
           accs[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, X[s2], accs[m & 1], 0, 0, 0);
         }
-        if (m > 0) {  // the previous tile's epilogue: 8 steps over KS1 MFMAs
+        if (m > 0) {  // the previous tile's epilogue: 8 steps over NSTEP MFMAs
 #pragma unroll
-          for (int q = (8 * s2) / KS1; q < (8 * (s2 + 1)) / KS1; ++q)
+          for (int q = (8 * j) / NSTEP; q < (8 * (j + 1)) / NSTEP; ++q)
             H1[2 * (m - 1) + (q >> 2)][q & 3] = epi(accs[(m - 1) & 1], q);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +328,9 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
       // need it at once)
 #pragma unroll
       for (int q = 0; q < 8; ++q) H1[14 + (q >> 2)][q & 3] = epi(accs[1], q);
-    }
+    };
+    if (KS1 > ND_SPARSE + 1 && n_data <= ND_SPARSE) layer1(std::integral_constant<int, (KS1 > ND_SPARSE + 1 ? ND_SPARSE : KS1)>{});
+    else layer1(std::integral_constant<int, KS1>{});
     RVO3D_MLP_STAMP(1)
     // ---- layer 2 + heads: H2^T = relu(W2 H1^T + b2), head^T += W3 H2^T ----
     f32x16 hd = {0};
@@ -354,7 +392,7 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
         }
       }
 #if RVO3D_MLP_XPREFETCH
-      if (pass + 1 < 2 * iters) request_rows(pass + 1);
+      if (pass + 1 < 2 * iters) request_rows(pass + 1, KS1);
 #endif
       // the last tile's epilogue and head products
       a3[0] = *reinterpret_cast<const bf16x8*>(w3l + 14 * 128);

@@ -127,8 +127,8 @@ def lib():
     L.rvo3d_policy_mlp_blob_bytes.argtypes = [i32]
     L.rvo3d_policy_mlp_blob_bytes.restype = C.c_int64
     L.rvo3d_policy_mlp_pack.argtypes = [C.POINTER(MlpWeights), C.POINTER(MlpWeights), i32, vp, vp]
-    L.rvo3d_policy_mlp_sample.argtypes = [vp, i32, vp, C.c_int64, C.c_int64, i32, vp, C.c_float, C.c_uint64,
-                                          C.c_uint64] + [vp] * 6
+    L.rvo3d_policy_mlp_sample.argtypes = [vp, i32, vp, C.c_int64, C.c_int64, vp, i32, i32, i32, vp, C.c_float,
+                                          C.c_uint64, C.c_uint64] + [vp] * 6
     L.rvo3d_reader_first_step.argtypes = [C.POINTER(GruReader), vp, C.c_int64, C.c_int64, vp, i32, C.c_int64, vp]
     L.rvo3d_rollout_account.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 8
     L.rvo3d_des_vel.argtypes = [vp, vp, vp]

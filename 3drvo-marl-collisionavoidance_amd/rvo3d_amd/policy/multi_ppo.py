@@ -316,8 +316,9 @@ class multi_ppo:
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
             if mode == "mlp":
                 mb = self.ac.mlp_blob()
+                # (the env's counts: column groups that are zero for all rows of a wave are skipped)
                 _lib.check(L.rvo3d_policy_mlp_sample(p(mb["blob"]), env.W, p(x), x.stride(0), E * N,
-                                                     1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
+                                                     p(buf.cnt[t]), 12, 9, 1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
                                                      ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
                            "rvo3d_policy_mlp_sample")
                 ac["step"] += 1

@@ -172,7 +172,11 @@ int rvo3d_policy_sample(const rvo3d_policy_heads *heads, int64_t rows, float std
  * rvo3d_policy_mlp_pack turns the nn.Linear tensors (float32, weight [out][in], as the modules store them; widths
  * obs_width -> 256 -> 256 -> 3 for the actor, -> 1 for the critic) into the device blob the kernel reads
  * (rvo3d_policy_mlp_blob_bytes(obs_width) bytes, 16-byte aligned; repack after every optimizer step).
- * obs [rows][obs_ld] float32, obs_width <= 126.  Noise as rvo3d_policy_sample: Philox4x32-10, counter (row, step). */
+ * obs [rows][obs_ld] float32, obs_width <= 126.  Noise as rvo3d_policy_sample: Philox4x32-10, counter (row, step).
+ * vo_count (optional, NULL = none): the env's count output [rows] for these rows.  A row of the env holds state_dim
+ * floats, then row_dim floats per velocity-obstacle row, max(vo_count, 1) of them, then zeros: with the counts the
+ * kernel neither loads nor multiplies the 16-float column groups that are zero for all 32 rows a wave holds (exactly
+ * the same sums: a zero activation adds nothing).  Pass NULL for rows that do not keep that promise. */
 typedef struct rvo3d_mlp_weights {
   const float *w1, *b1; /* [256][obs_width], [256] */
   const float *w2, *b2; /* [256][256], [256] */
@@ -182,7 +186,7 @@ int64_t rvo3d_policy_mlp_blob_bytes(int32_t obs_width);
 int rvo3d_policy_mlp_pack(const rvo3d_mlp_weights *pi, const rvo3d_mlp_weights *v, int32_t obs_width, void *blob,
                           void *stream);
 int rvo3d_policy_mlp_sample(const void *blob, int32_t obs_width, const float *obs, int64_t obs_ld, int64_t rows,
-                            int32_t tanh_out, const float *log_std, float std_factor, uint64_t seed, uint64_t step,
+                            const int32_t *vo_count, int32_t state_dim, int32_t row_dim, int32_t tanh_out, const float *log_std, float std_factor, uint64_t seed, uint64_t step,
                             float *act, float *logp, float *val, float *dbg_mu, float *dbg_raw, void *stream);
 
 /* rnn_Reader.obs_rnn (train/policy/policy_rnn_ac.py:75-127) for observations with AT MOST ONE velocity-obstacle row

@@ -94,7 +94,7 @@ def _mlp_pack(ac, W):
     return blob
 
 
-def _mlp_sample(blob, W, x, log_std, tanh=True, seed=7, step=0, std_factor=1.0, rows=None):
+def _mlp_sample(blob, W, x, log_std, tanh=True, seed=7, step=0, std_factor=1.0, rows=None, cnt=None):
     L = _lib.lib()
     rows = x.shape[0] if rows is None else rows
     act = torch.full((rows, 3), 9.0, device=DEV)
@@ -102,7 +102,7 @@ def _mlp_sample(blob, W, x, log_std, tanh=True, seed=7, step=0, std_factor=1.0, 
     val = torch.full((rows,), 9.0, device=DEV)
     mu = torch.zeros((rows, 3), device=DEV)
     raw = torch.zeros((rows, 3), device=DEV)
-    _lib.check(L.rvo3d_policy_mlp_sample(_p(blob), W, _p(x), x.stride(0), rows, 1 if tanh else 0, _p(log_std), std_factor,
+    _lib.check(L.rvo3d_policy_mlp_sample(_p(blob), W, _p(x), x.stride(0), rows, _p(cnt), 12, 9, 1 if tanh else 0, _p(log_std), std_factor,
                                          seed, step, _p(act), _p(logp), _p(val), _p(mu), _p(raw),
                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "rvo3d_policy_mlp_sample")
     torch.cuda.synchronize()
@@ -205,6 +205,36 @@ def test_policy_mlp_sample_matches_torch(W, rows):
     assert torch.allclose(_mlp_sample(_mlp_pack(ac, W), W, x, log_std)[2], val + 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("nm", [10, 5, 3])
+def test_policy_mlp_sample_skips_zero_column_groups_exactly(nm):
+    """With the env's vo_count the kernel neither loads nor multiplies the 16-float column groups that are zero for all
+    32 rows of a wave: a zero activation adds exactly nothing, so the results must be BIT-IDENTICAL to the dense pass -
+    on rows shaped like the env's (12 floats, 9 per kept VO row, zeros behind; count 0 = one all-zero row), with every
+    mixture of counts inside a 32-row group: all sparse, one dense row among sparse ones, all dense."""
+    W, rows = 12 + 9 * nm, 64 * 50 + 17
+    g = torch.Generator(device=DEV).manual_seed(nm)
+    ac = mlp_ac(W).to(DEV)
+    cnt = torch.randint(0, 3, (rows,), device=DEV, generator=g, dtype=torch.int32)
+    cnt[torch.rand(rows, device=DEV, generator=g) < 0.02] = nm           # a dense row here and there
+    cnt[64 * 7:64 * 9] = torch.randint(0, nm + 1, (128,), device=DEV, generator=g, dtype=torch.int32)  # two mixed groups
+    cnt[64 * 20:64 * 21] = nm                                             # one all-dense group
+    cnt[64 * 30:64 * 32] = 0                                              # all-empty groups
+    x = torch.randn((rows, W), device=DEV, generator=g)
+    used = 12 + 9 * cnt.clamp(min=0).long()
+    x *= (torch.arange(W, device=DEV)[None, :] < used[:, None]).float()
+    log_std = torch.tensor([-1.0, -0.5, -1.5], device=DEV)
+    blob = _mlp_pack(ac, W)
+    dense = _mlp_sample(blob, W, x, log_std)
+    sparse = _mlp_sample(blob, W, x, log_std, cnt=cnt)
+    for a, b in zip(dense, sparse):
+        assert torch.equal(a, b)
+    z_emu, v_emu = _mlp_emulation(ac, x)
+    assert float((sparse[3] - torch.tanh(z_emu)).abs().max()) < 1e-2 and float((sparse[2] - v_emu).abs().max()) < 1e-2
+    L = _lib.lib()
+    assert L.rvo3d_policy_mlp_sample(_p(blob), W, _p(x), W, rows, _p(cnt), W + 1, 9, 1, _p(log_std), 1.0, 0, 0,
+                                     _p(dense[0]), _p(dense[1]), _p(dense[2]), None, None, None) == -1
+
+
 def test_policy_mlp_sample_reads_only_the_callers_bytes_and_rejects_bad_arguments():
     """The 16-wide k-steps run past the last row's end: the kernel reads through a buffer descriptor of exactly
     (rows - 1) ld + width floats.  Here the observation array ends flush with its allocation and is followed by NaNs in
@@ -224,7 +254,7 @@ def test_policy_mlp_sample_reads_only_the_callers_bytes_and_rejects_bad_argument
     c = _mlp_sample(blob, W, x, log_std, rows=77)
     assert torch.equal(c[3], a[3][:77]) and torch.equal(c[2], a[2][:77])
     v = torch.zeros(8, device=DEV)
-    args = lambda **k: [k.get("blob", _p(blob)), k.get("W", W), _p(x), k.get("ld", W), k.get("rows", rows), 1, _p(log_std),
+    args = lambda **k: [k.get("blob", _p(blob)), k.get("W", W), _p(x), k.get("ld", W), k.get("rows", rows), None, 12, 9, 1, _p(log_std),
                         1.0, 0, 0, _p(v), _p(v), _p(v), None, None, None]
     assert L.rvo3d_policy_mlp_sample(*args(W=127)) == -1 and b"obs_width" in L.rvo3d_last_error()
     assert L.rvo3d_policy_mlp_sample(*args(ld=W - 1)) == -1

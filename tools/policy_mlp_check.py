@@ -15,6 +15,7 @@ from rvo3d_amd.policy import mlp_ac
 L = _lib.lib()
 torch.manual_seed(0)
 dev = "cuda"
+CNT = None
 def pack(ac, W):
     nb = L.rvo3d_policy_mlp_blob_bytes(W)
     blob = torch.zeros(nb, dtype=torch.uint8, device=dev)
@@ -45,7 +46,7 @@ for (W, B) in [(102, 64), (102, 1000), (102, 262144), (57, 5000), (39, 777), (12
     x = torch.randn(B, W, device=dev) * 2
     act = torch.zeros(B, 3, device=dev); logp = torch.zeros(B, device=dev); val = torch.zeros(B, device=dev)
     mu = torch.zeros(B, 3, device=dev); raw = torch.zeros(B, 3, device=dev)
-    _lib.check(L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, 1, ac.log_std.data_ptr(), 1.0,
+    _lib.check(L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, CNT, 12, 9, 1, ac.log_std.data_ptr(), 1.0,
                                          1234, 5, act.data_ptr(), logp.data_ptr(), val.data_ptr(), mu.data_ptr(),
                                          raw.data_ptr(), None), "sample")
     torch.cuda.synchronize()
@@ -61,14 +62,28 @@ x = torch.randn(B, W, device=dev)
 act = torch.zeros(B, 3, device=dev); logp = torch.zeros(B, device=dev); val = torch.zeros(B, device=dev)
 def run(n):
     for i in range(n):
-        L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, 1, ac.log_std.data_ptr(), 1.0,
+        L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, CNT, 12, 9, 1, ac.log_std.data_ptr(), 1.0,
                                   1234, i, act.data_ptr(), logp.data_ptr(), val.data_ptr(), None, None, None)
-run(5); torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); run(50); e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 50 * 1e3
-fl = 2 * B * 2 * (112 * 256 + 256 * 256 + 256 * 32)
-print(f"policy_mlp_sample {B} rows: {us:.1f} us per call, {fl / us / 1e6:.0f} TFLOP/s issued")
+def timed(tag):
+    run(5); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); run(50); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 50 * 1e3
+    fl = 2 * B * 2 * (112 * 256 + 256 * 256 + 256 * 32)
+    print(f"policy_mlp_sample {B} rows, {tag}: {us:.1f} us per call ({fl / us / 1e6:.0f} TFLOP/s counting every k-step)")
+timed("dense rows (no counts)")
+# rows as a rollout of the bench world has them: the counts of a real env after 50 random steps
+from rvo3d_amd import BatchedDroneEnv, synthetic_world
+env = BatchedDroneEnv(synthetic_world(4096, 64, (50, 50, 10)))
+env.reset(); env.observe()
+for _ in range(50):
+    env.step_policy(torch.rand((4096, 64, 3), device=dev) * 2 - 1, autoreset=True)
+x = env.obs.view(B, W).clone(); CNT = env.vo_count.view(B).clone().data_ptr(); cnt_t = env.vo_count.view(B)
+hist = torch.bincount(cnt_t.long().clamp(min=0), minlength=4)[:4].tolist()
+print(f"env rows after 50 steps: vo_count 0 / 1 / 2 / 3: {hist} of {B}")
+timed("the env's rows with their counts")
+CNT = None
+timed("the env's rows without counts")
 if os.environ.get("MLP_CLOCK"):
     torch.cuda.synchronize()
     a = act[0].tolist()
@@ -76,7 +91,7 @@ if os.environ.get("MLP_CLOCK"):
 if os.environ.get("MLP_CLOCK"):
     import numpy as np
     dbg = torch.zeros(B * 3, device=dev)
-    L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, 1, ac.log_std.data_ptr(), 1.0,
+    L.rvo3d_policy_mlp_sample(blob.data_ptr(), W, x.data_ptr(), x.stride(0), B, CNT, 12, 9, 1, ac.log_std.data_ptr(), 1.0,
                               1234, 0, act.data_ptr(), logp.data_ptr(), val.data_ptr(), dbg.data_ptr(), None, None)
     torch.cuda.synchronize()
     NWV = int(os.environ.get("MLP_NW", "8")); d = dbg[:256 * NWV * 4].view(256, NWV, 4).cpu().numpy()

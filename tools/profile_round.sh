@@ -29,4 +29,8 @@ python tools/rollout_profile.py > $OUT/rollout_step_kernels.txt 2>/dev/null
 tools/ubench/hbm_rate warm > $OUT/hbm_rate_ubench.txt 2>&1; tools/ubench/hbm_rate >> $OUT/hbm_rate_ubench.txt 2>&1
 python tools/stamps.py > $OUT/stamps_cfg3_warm.txt 2>&1; STAMPS_COLD=rw python tools/stamps.py > $OUT/stamps_cfg3_cold.txt 2>&1
 python tools/bench_aux.py > $OUT/aux_kernels.txt 2>&1
+python tools/policy_mlp_check.py > $OUT/policy_mlp_check.txt 2>/dev/null
+python tools/update_profile.py --no-split > $OUT/update_kernels_before_split.txt 2>/dev/null
+python tools/update_profile.py > $OUT/update_kernels.txt 2>/dev/null
+bash tools/pmc_policy_mlp.sh > /dev/null 2>&1; cp gpurun_out/pmc_policy_mlp/summary.txt $OUT/policy_mlp_pmc_summary.txt
 ls $OUT
