@@ -311,11 +311,11 @@ class multi_ppo:
         since_full_reset = 0
         mode = self._fused_mode()
         log_std = self.ac.log_std
+        mb = self.ac.mlp_blob() if mode == "mlp" else None  # (once per rollout: the weights do not change inside it)
         for t in range(T):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
             if mode == "mlp":
-                mb = self.ac.mlp_blob()
                 # (the env's counts: column groups that are zero for all rows of a wave are skipped)
                 _lib.check(L.rvo3d_policy_mlp_sample(p(mb["blob"]), env.W, p(x), x.stride(0), E * N,
                                                      p(buf.cnt[t]), 12, 9, 1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
