@@ -7,6 +7,7 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/pmc_policy_mlp
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export MLP_DENSE_ONLY=1   # dense rows: every k-step of every pass
 run() { # name counters...
   n=$1; shift
   timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- python3 $ROOT/tools/policy_mlp_check.py $LIBV > $OUT/$n.log 2>&1
@@ -22,7 +23,7 @@ for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
         if "policy_mlp_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 256 * 512:
             a = agg[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
 c = {k: v / n for k, (v, n) in agg.items()}
-print("policy_mlp_kernel<7, 8>, 262144 rows, per launch (mean over %d launches; quad-cycle counters x 4):" % agg["SQ_WAVES"][1])
+print("policy_mlp_kernel<7, 8>, 262144 dense rows (no counts: 1600 MFMAs per wave), per launch (mean over %d launches; quad-cycle counters x 4):" % agg["SQ_WAVES"][1])
 w = c["SQ_WAVES"]
 print("  waves %d, MFMA instructions %.0f per wave, other VALU %.0f, LDS %.0f, VMEM reads %.0f, SALU %.0f per wave" % (
     w, c["SQ_INSTS_MFMA"] / w, (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / w, c["SQ_INSTS_LDS"] / w, c["SQ_INSTS_VMEM_RD"] / w, c["SQ_INSTS_SALU"] / w))

@@ -72,6 +72,8 @@ def timed(tag):
     fl = 2 * B * 2 * (112 * 256 + 256 * 256 + 256 * 32)
     print(f"policy_mlp_sample {B} rows, {tag}: {us:.1f} us per call ({fl / us / 1e6:.0f} TFLOP/s counting every k-step)")
 timed("dense rows (no counts)")
+if os.environ.get("MLP_DENSE_ONLY"):      # (tools/pmc_policy_mlp.sh: counters of ONE regime)
+    sys.exit(0)
 # rows as a rollout of the bench world has them: the counts of a real env after 50 random steps
 from rvo3d_amd import BatchedDroneEnv, synthetic_world
 env = BatchedDroneEnv(synthetic_world(4096, 64, (50, 50, 10)))
