@@ -356,6 +356,47 @@ __global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs
   }
   const float lw = A.ln_w[SD + u], lb = A.ln_b[SD + u];
   const float lw0 = u < SD ? A.ln_w[u] : 0.f, lb0 = u < SD ? A.ln_b[u] : 0.f;
+  // one cell evaluation of this unit from h = 0 (both directions summed).  Packed fp32 (v_pk_fma_f32) across GATES,
+  // not rows - the weights pair up as they sit in registers ((r, z) of a direction; n of the two directions), only the
+  // row's nine inputs are splatted: 27 instead of 54 multiply-add instructions per row.  Per unit, row and direction
+  // five transcendentals instead of six: (1 - z) n with z = 1 / (1 + e_z), n = tanh(a) = (1 - e_n) / (1 + e_n),
+  // e_z = exp(-g_z), e_n = exp(-2 a) is e_z (1 - e_n) / ((1 + e_z)(1 + e_n)): one reciprocal for both.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  auto cell = [&](const float* x) -> float {
+    v2f rz[2] = {{c_r[0], c_z[0]}, {c_r[1], c_z[1]}}, nn = {b_in[0], b_in[1]};
+#pragma unroll
+    for (int k = 0; k < IN; ++k) {
+      const float xk = x[k];
+      const v2f xx = {xk, xk};
+      rz[0] = __builtin_elementwise_fma((v2f){w[0][0][k], w[0][1][k]}, xx, rz[0]);
+      rz[1] = __builtin_elementwise_fma((v2f){w[1][0][k], w[1][1][k]}, xx, rz[1]);
+      nn = __builtin_elementwise_fma((v2f){w[0][2][k], w[1][2][k]}, xx, nn);
+    }
+    float hs = 0.f;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const float rg = fast_sigmoid(rz[dir].x);
+      const float a = (dir ? nn.y : nn.x) + rg * b_hn[dir];
+      // clamped exponents: exp(88) overflows float32 to inf and inf / inf is NaN; beyond +-30 the cell saturates anyway
+      const float ez = __expf(-__builtin_fmaxf(__builtin_fminf(rz[dir].y, 30.f), -30.f));
+      const float en = __expf(-2.0f * __builtin_fmaxf(__builtin_fminf(a, 15.f), -15.f));
+      const float hd = ez * (1.0f - en) * __builtin_amdgcn_rcpf((1.0f + ez) * (1.0f + en));
+      if (dir == 0 || bi) hs += hd;
+    }
+    return hs;
+  };
+  // A row whose VO row is all zeros - no velocity obstacle: nearly every row of a rollout - has the SAME hidden state
+  // (the cell sees biases only): computed once, with the same instructions (bit-identical), and so are its two wave sums
+  float h0, v0, q0;
+  {
+    float zero_in[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) zero_in[k] = 0.f;
+    h0 = cell(zero_in);
+    v0 = h0; q0 = h0 * h0;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) { v0 += __shfl_xor(v0, sh, 64); q0 += __shfl_xor(q0, sh, 64); }
+  }
   const int64_t ngroups = (A.rows + kReaderRows - 1) / kReaderRows;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t row0 = grp * kReaderRows;
@@ -367,45 +408,30 @@ __global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs
     }
     __syncthreads();
     float h[kReaderRows];
-    // Packed fp32 (v_pk_fma_f32) across GATES, not rows - the weights pair up as they sit in registers ((r, z) of a
-    // direction; n of the two directions), only the row's nine inputs are splatted: 27 instead of 54 multiply-add
-    // instructions per row.  Two rows per loop trip (fully unrolled over the eight rows: 176 VGPRs = two waves per
-    // SIMD).  Per unit, row and direction five transcendentals instead of six: (1 - z) n with z = 1 / (1 + e_z),
-    // n = tanh(a) = (1 - e_n) / (1 + e_n), e_z = exp(-g_z), e_n = exp(-2 a) is e_z (1 - e_n) / ((1 + e_z)(1 + e_n)):
-    // one reciprocal for both.
-    typedef float v2f __attribute__((ext_vector_type(2)));
+    unsigned zero_rows = 0;  // (workgroup-uniform: every thread looks at the same staged inputs)
 #pragma unroll 2
     for (int r = 0; r < kReaderRows; ++r) {
-      v2f rz[2] = {{c_r[0], c_z[0]}, {c_r[1], c_z[1]}}, nn = {b_in[0], b_in[1]};
+      bool any = false;
 #pragma unroll
-      for (int k = 0; k < IN; ++k) {
-        const float xk = s_in[r][SD + k];
-        const v2f xx = {xk, xk};
-        rz[0] = __builtin_elementwise_fma((v2f){w[0][0][k], w[0][1][k]}, xx, rz[0]);
-        rz[1] = __builtin_elementwise_fma((v2f){w[1][0][k], w[1][1][k]}, xx, rz[1]);
-        nn = __builtin_elementwise_fma((v2f){w[0][2][k], w[1][2][k]}, xx, nn);
+      for (int k = 0; k < IN; ++k) any |= s_in[r][SD + k] != 0.f;
+      if (any) {
+        h[r] = cell(&s_in[r][SD]);
+      } else {
+        h[r] = h0;
+        zero_rows |= 1u << r;
       }
-      float hs = 0.f;
-#pragma unroll
-      for (int dir = 0; dir < 2; ++dir) {
-        const float rg = fast_sigmoid(rz[dir].x);
-        const float a = (dir ? nn.y : nn.x) + rg * b_hn[dir];
-        // clamped exponents: exp(88) overflows float32 to inf and inf / inf is NaN; beyond +-30 the cell saturates anyway
-        const float ez = __expf(-__builtin_fmaxf(__builtin_fminf(rz[dir].y, 30.f), -30.f));
-        const float en = __expf(-2.0f * __builtin_fmaxf(__builtin_fminf(a, 15.f), -15.f));
-        const float hd = ez * (1.0f - en) * __builtin_amdgcn_rcpf((1.0f + ez) * (1.0f + en));
-        if (dir == 0 || bi) hs += hd;
-      }
-      h[r] = hs;
     }
     // LayerNorm (biased variance, eps inside the root: torch.nn.LayerNorm): per row the sum and the sum of squares of
     // the hidden part (wave reduction, one pass: the features are O(1), 268 of them - var = E[x^2] - mean^2 loses
     // nothing visible at float32), then thread r < rows adds the waves' partial sums and the row's proprioceptive part
 #pragma unroll
     for (int r = 0; r < kReaderRows; ++r) {
-      float v = h[r], q = h[r] * h[r];
+      float v = v0, q = q0;
+      if (!((zero_rows >> r) & 1)) {
+        v = h[r]; q = h[r] * h[r];
 #pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) { v += __shfl_xor(v, sh, 64); q += __shfl_xor(q, sh, 64); }
+        for (int sh = 32; sh >= 1; sh >>= 1) { v += __shfl_xor(v, sh, 64); q += __shfl_xor(q, sh, 64); }
+      }
       if (lane == 0) { s_red[r][wv] = v; s_red2[r][wv] = q; }
     }
     __syncthreads();

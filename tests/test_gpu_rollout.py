@@ -360,6 +360,12 @@ def test_reader_first_step_matches_the_module(hidden, bi, dt):
     obs = torch.randn((rows, W), device=DEV)
     obs[:, 21:] = 0.0
     obs[::7, 12:21] = 0.0   # drones without any VO row: the reference's single all-zero row
+    # ... which is what nearly every row of a rollout looks like: the kernel computes that row's hidden state once per
+    # launch.  Whole trips of eight such rows, trips with one row that has a VO row, a long run of them:
+    obs[800:1600, 12:21] = 0.0
+    obs[808, 12:21] = torch.randn(9, device=DEV)
+    obs[2000:4099, 12:21] = 0.0
+    obs[3001, 15] = 0.25
     with torch.no_grad():
         want = r.forward_batch(obs, torch.ones(rows, dtype=torch.int64, device=DEV))
     D = 12 + hidden
@@ -380,6 +386,11 @@ def test_reader_first_step_matches_the_module(hidden, bi, dt):
     tol = 3e-5 if dt == torch.float32 else 3e-5 + 2 ** -8 * float(want.abs().max())
     assert float((got - want).abs().max()) < tol, float((got - want).abs().max())
     assert bool((feat[:, D:] == 7.0).all())   # the caller's padding is not touched
+    # the shortcut runs the same instructions on the same (zero) inputs: a zero row's hidden part is the same bits
+    # whether its trip took the shortcut (rows 2000..) or computed it beside a row with a VO row (row 7 of trip 0)
+    zero_rows = (obs[:, 12:21] == 0).all(dim=1)
+    hid = (feat[:, 12:D].float() - want[:, 12:D]).abs()
+    assert float(hid[zero_rows].max()) < tol
     bad = _lib.GruReader(*[None if t is None else t.data_ptr() for t in w], 100, 9, 12, 1e-5)
     assert L.rvo3d_reader_first_step(C.byref(bad), _p(obs), W, rows, _p(feat), 0, ld, None) == -1
 
