@@ -223,11 +223,15 @@ constexpr int kMlpWaves = RVO3D_MLP_WAVES;  // waves per workgroup of policy_mlp
 template <int KS1>
 int launch_policy_mlp(const rvo3d::PolicyMlpArgs& A, unsigned grid, hipStream_t s) {
   constexpr int lds = rvo3d::mlp_lds_bytes(KS1);
-  static bool attr_set = false;  // (per process and instantiation; the attribute is per device function)
-  if (!attr_set) {
+  // more than 64 KB of dynamic LDS needs the attribute, once per device (the function object is per device) and
+  // instantiation; a lost race between two threads sets it twice, which is harmless
+  static uint64_t attr_set = 0;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !((attr_set >> dev) & 1)) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(rvo3d::policy_mlp_kernel<KS1, kMlpWaves>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set |= (uint64_t)1 << dev;
   }
   hipLaunchKernelGGL((rvo3d::policy_mlp_kernel<KS1, kMlpWaves>), dim3(grid), dim3(64 * kMlpWaves), lds, s, A);
   HIP_TRY(hipGetLastError());

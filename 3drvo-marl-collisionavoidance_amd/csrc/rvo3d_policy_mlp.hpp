@@ -114,7 +114,7 @@ struct PolicyMlpArgs {
   const float* obs;           // [rows][ld_obs] float32: the env's observation rows
   int64_t ld_obs;
   int32_t k_in;               // observation width (12 + 9 nm)
-  const int32_t* cnt;         // optional [rows]: the env's vo_count - a row holds state_dim + row_dim * max(cnt, 1) floats, zeros behind
+  const int32_t* cnt;         // optional [rows]: the env's vo_count - a row holds state_dim + row_dim * cnt floats, zeros behind
   int32_t state_dim, row_dim; // 12, 9
   PolicySampleArgs S;         // tanh_out, log_std, std_factor, seed, step, rows, act / logp / val, dbg_*
 };
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
     int64_t row = c * 64 + 32 * (pass & 1) + r;
     if (row >= rows) row = rows - 1;
     int cn = A.cnt[row];
-    cn = cn < 1 ? 1 : cn;
+    cn = cn < 0 ? 0 : cn;  // (count 0 = the single all-zero row: no data behind the state)
     const int mine = (A.state_dim + A.row_dim * cn + 15) >> 4;
     int n = 1;
 #pragma unroll
@@ -287,8 +287,9 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
     f32x16 accs[2];
     bf16x8 S[NS];  // the streamed fragments of the next second-layer tile
     // ---- layer 1: H1^T = relu(W1 X^T): one flat stream of fragments out of LDS ----
-    // Two straight-line versions, chosen per pass (wave-uniform): every k-step, or - rows whose data ends within the
-    // first ND_SPARSE k-steps, i.e. at most two kept VO rows: nearly all of a rollout - those plus the bias step.
+    // Three straight-line versions, chosen per pass (wave-uniform): every k-step; the first ND_SPARSE k-steps (rows with
+    // at most two kept VO rows) plus the bias step; the first k-step (rows without any: nearly all of a rollout) plus
+    // the bias step.
     constexpr int ND_SPARSE = 2;
     auto layer1 = [&](auto nd_tag) {
       constexpr int ND = decltype(nd_tag)::value;                  // leading k-steps with data
@@ -329,7 +330,8 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
 #pragma unroll
       for (int q = 0; q < 8; ++q) H1[14 + (q >> 2)][q & 3] = epi(accs[1], q);
     };
-    if (KS1 > ND_SPARSE + 1 && n_data <= ND_SPARSE) layer1(std::integral_constant<int, (KS1 > ND_SPARSE + 1 ? ND_SPARSE : KS1)>{});
+    if (KS1 > ND_SPARSE + 1 && n_data <= 1) layer1(std::integral_constant<int, (KS1 > ND_SPARSE + 1 ? 1 : KS1)>{});
+    else if (KS1 > ND_SPARSE + 1 && n_data <= ND_SPARSE) layer1(std::integral_constant<int, (KS1 > ND_SPARSE + 1 ? ND_SPARSE : KS1)>{});
     else layer1(std::integral_constant<int, KS1>{});
     RVO3D_MLP_STAMP(1)
     // ---- layer 2 + heads: H2^T = relu(W2 H1^T + b2), head^T += W3 H2^T ----

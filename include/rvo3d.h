@@ -174,7 +174,7 @@ int rvo3d_policy_sample(const rvo3d_policy_heads *heads, int64_t rows, float std
  * (rvo3d_policy_mlp_blob_bytes(obs_width) bytes, 16-byte aligned; repack after every optimizer step).
  * obs [rows][obs_ld] float32, obs_width <= 126.  Noise as rvo3d_policy_sample: Philox4x32-10, counter (row, step).
  * vo_count (optional, NULL = none): the env's count output [rows] for these rows.  A row of the env holds state_dim
- * floats, then row_dim floats per velocity-obstacle row, max(vo_count, 1) of them, then zeros: with the counts the
+ * floats, then row_dim floats per velocity-obstacle row, vo_count of them, then zeros: with the counts the
  * kernel neither loads nor multiplies the 16-float column groups that are zero for all 32 rows a wave holds (exactly
  * the same sums: a zero activation adds nothing).  Pass NULL for rows that do not keep that promise. */
 typedef struct rvo3d_mlp_weights {
