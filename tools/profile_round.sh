@@ -26,6 +26,7 @@ bash tools/bench_all.sh $R > /dev/null 2>&1; cp gpurun_out/bench_all_$R.txt $OUT
 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python tools/bench_rollout.py --amp --steps 16 > $OUT/rollout_bench.json 2>/dev/null
 python tools/rollout_profile.py > $OUT/rollout_step_kernels.txt 2>/dev/null
+python tools/rollout_profile.py --policy rnn > $OUT/rollout_step_kernels_rnn.txt 2>/dev/null
 tools/ubench/hbm_rate warm > $OUT/hbm_rate_ubench.txt 2>&1; tools/ubench/hbm_rate >> $OUT/hbm_rate_ubench.txt 2>&1
 python tools/stamps.py > $OUT/stamps_cfg3_warm.txt 2>&1; STAMPS_COLD=rw python tools/stamps.py > $OUT/stamps_cfg3_cold.txt 2>&1
 python tools/bench_aux.py > $OUT/aux_kernels.txt 2>&1
