@@ -747,6 +747,63 @@ int rvo3d_policy_mlp_sample(const void* blob, int32_t obs_width, const float* ob
   RVO3D_API_END
 }
 
+int rvo3d_reader_zero_features(const float* obs, int64_t obs_ld, int64_t rows, int32_t state_dim, int32_t feat_dim,
+                               const float* ln_w, const float* ln_b, float sum_h0, float sumsq_h0, float ln_eps,
+                               float* out, int64_t out_ld, const int32_t* vo_count, int32_t* list, int32_t* count,
+                               void* stream) {
+  RVO3D_API_BEGIN
+  if (!obs || !ln_w || !ln_b || !out) return fail(RVO3D_ERR_INVALID, "null pointer");
+  if ((vo_count != nullptr) != (list != nullptr) || (vo_count != nullptr) != (count != nullptr))
+    return fail(RVO3D_ERR_INVALID, "vo_count, list and count go together");
+  if (state_dim < 1 || state_dim > rvo3d::kReaderMaxSd || feat_dim <= state_dim)
+    return fail(RVO3D_ERR_INVALID, "need 1 <= state_dim <= 32 and feat_dim > state_dim");
+  if (rows < 0 || obs_ld < state_dim || out_ld < state_dim + 8) return fail(RVO3D_ERR_INVALID, "rows / row strides too small");
+  if (rows == 0) return RVO3D_OK;
+  rvo3d::ZeroFeatArgs A{obs, obs_ld, rows, state_dim, feat_dim, ln_w, ln_b, sum_h0, sumsq_h0, ln_eps, out, out_ld,
+                        vo_count, list, count};
+  hipLaunchKernelGGL(rvo3d::reader_zero_features_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
+int rvo3d_policy_rows(const rvo3d_rnn_policy* net, const float* obs, int64_t obs_ld, const int32_t* vo_count,
+                      const int32_t* list, int32_t* count, int32_t* done_blocks, int32_t tanh_out, const float* log_std,
+                      float std_factor, uint64_t seed, uint64_t step, float* act, float* logp, float* val, void* stream) {
+  RVO3D_API_BEGIN
+  if (!net || !obs || !vo_count || !list || !count || !done_blocks || !log_std || !act || !logp || !val)
+    return fail(RVO3D_ERR_INVALID, "null pointer");
+  if (!net->w_ih_f || !net->w_hh_f || !net->b_ih_f || !net->b_hh_f || !net->ln_w || !net->ln_b)
+    return fail(RVO3D_ERR_INVALID, "null reader weight");
+  const bool bi = net->w_ih_r != nullptr;
+  if (bi != (net->w_hh_r != nullptr) || bi != (net->b_ih_r != nullptr) || bi != (net->b_hh_r != nullptr))
+    return fail(RVO3D_ERR_INVALID, "the reverse direction needs all four of w_ih_r / w_hh_r / b_ih_r / b_hh_r");
+  if (net->hidden < 1 || net->hidden > 256 || net->in_dim < 1 || net->in_dim > rvo3d::kReaderMaxIn || net->state_dim < 1 ||
+      net->state_dim > rvo3d::kReaderMaxSd || net->slots < 1 || net->slots > 16)
+    return fail(RVO3D_ERR_INVALID, "hidden <= 256, in_dim <= 16, state_dim <= 32, slots <= 16");
+  if (obs_ld < net->state_dim + net->slots * net->in_dim) return fail(RVO3D_ERR_INVALID, "obs_ld too small");
+  const rvo3d_mlp_weights* m[2] = {&net->pi, &net->v};
+  rvo3d::PolicyRowsArgs A;
+  A.obs = obs; A.obs_ld = obs_ld; A.cnt = vo_count; A.list = list; A.count = count; A.done_blocks = done_blocks;
+  A.state_dim = net->state_dim; A.in_dim = net->in_dim; A.H = net->hidden; A.slots = net->slots;
+  A.w_ih[0] = net->w_ih_f; A.w_hh[0] = net->w_hh_f; A.b_ih[0] = net->b_ih_f; A.b_hh[0] = net->b_hh_f;
+  A.w_ih[1] = net->w_ih_r; A.w_hh[1] = net->w_hh_r; A.b_ih[1] = net->b_ih_r; A.b_hh[1] = net->b_hh_r;
+  A.ln_w = net->ln_w; A.ln_b = net->ln_b; A.eps = net->ln_eps;
+  for (int i = 0; i < 2; ++i) {
+    if (!m[i]->w1 || !m[i]->b1 || !m[i]->w2 || !m[i]->b2 || !m[i]->w3 || !m[i]->b3)
+      return fail(RVO3D_ERR_INVALID, "null head weight");
+    A.w1[i] = m[i]->w1; A.b1[i] = m[i]->b1; A.w2[i] = m[i]->w2; A.b2[i] = m[i]->b2; A.w3[i] = m[i]->w3; A.b3[i] = m[i]->b3;
+  }
+  A.S = rvo3d::PolicySampleArgs{};
+  A.S.tanh_out = tanh_out; A.S.log_std = log_std; A.S.std_factor = std_factor; A.S.seed = seed; A.S.step = step;
+  A.S.act = act; A.S.logp = logp; A.S.val = val;
+  hipLaunchKernelGGL(rvo3d::policy_rows_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+  HIP_TRY(hipGetLastError());
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
 int rvo3d_reader_first_step(const rvo3d_gru_reader* rd, const float* obs, int64_t obs_ld, int64_t rows, void* feat,
                             int32_t feat_dtype, int64_t feat_ld, void* stream) {
   RVO3D_API_BEGIN

@@ -486,4 +486,200 @@ __global__ void __launch_bounds__(256) reader_first_step_kernel(const ReaderArgs
   }
 }
 
+// ---- the reader's features of a row WITHOUT a velocity-obstacle row, collapsed ------------------------------------
+// For such a row the GRU sees a zero input from h = 0: its hidden state h0 is the same for every row, and the
+// LayerNorm of concat(p, h0) (p: the row's state_dim proprioceptive floats) depends on the row through two scalars
+// only, mean and rstd:  f_p = (p - mean) rstd g_p + b_p,  f_h = rstd (h0 g_h) - mean rstd g_h + b_h.  A linear layer on
+// those features is therefore  W_p f_p + rstd a - (mean rstd) b + c  with a = W_h (h0 g_h), b = W_h g_h, c = W_h b_h + bias
+// - a product over state_dim + 3 inputs instead of state_dim + hidden.  This kernel writes, per row, the inputs of
+// that product for rvo3d_policy_mlp_sample: f_p, then rstd and mean rstd each as bf16 head / head / tail (so that the
+// bf16 products a_hi r_hi + a_lo r_hi + a_hi r_lo carry ~16 bits of each factor), then two ones (for c's head and tail).
+struct ZeroFeatArgs {
+  const float* obs; int64_t obs_ld, rows;
+  int32_t state_dim, feat_dim;     // 12, state_dim + hidden
+  const float* ln_w; const float* ln_b;  // LayerNorm affine: the first state_dim entries are used
+  float sum_h0, sumsq_h0, eps;
+  float* out; int64_t out_ld;      // [rows][>= state_dim + 8]
+  const int32_t* cnt;              // optional [rows]: rows with cnt > 0 are appended to `list` (order: as the atomics fall)
+  int32_t* list; int32_t* count;   // [rows], [1] (zero before the launch; policy_rows_kernel resets it)
+};
+__device__ __forceinline__ float bf16_head(float x) {
+  return __builtin_bit_cast(float, (uint32_t)f32_to_bf16_rne(x) << 16);
+}
+__global__ void __launch_bounds__(256) reader_zero_features_kernel(const ZeroFeatArgs A) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= A.rows) return;
+  const float* p = A.obs + row * A.obs_ld;
+  float x[kReaderMaxSd];
+  // (16 bytes per load instruction: a wave's lanes sit a whole observation row apart, so every load instruction
+  // touches 64 cache lines - the fewer instructions the better: 51 -> 17 us at 262144 rows)
+#pragma unroll
+  for (int q = 0; q < kReaderMaxSd / 4; ++q)
+    if (4 * q < A.state_dim) __builtin_memcpy(&x[4 * q], p + 4 * q, 16);  // (may read up to 3 floats past state_dim: still this row)
+  float t = A.sum_h0, t2 = A.sumsq_h0;
+#pragma unroll
+  for (int k = 0; k < kReaderMaxSd; ++k)
+    if (k < A.state_dim) { t += x[k]; t2 += x[k] * x[k]; }
+  const float D = (float)A.feat_dim;
+  const float mean = t / D;
+  const float var = __builtin_fmaxf(t2 / D - mean * mean, 0.f);
+  const float rstd = 1.0f / __builtin_sqrtf(var + A.eps);
+  float* o = A.out + row * A.out_ld;
+  const float m = mean * rstd;
+  const float rh = bf16_head(rstd), mh = bf16_head(m);
+  const float tail[8] = {rh, rh, rstd - rh, mh, mh, m - mh, 1.0f, 1.0f};
+  if (A.state_dim == 12 && (A.out_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(A.out) & 15) == 0) {
+    // (the env's shape: 20 floats per row leave as five 16-byte stores, not twenty 4-byte ones a row apart each)
+    float y[20];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) y[k] = (x[k] - mean) * rstd * A.ln_w[k] + A.ln_b[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) y[12 + k] = tail[k];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) reinterpret_cast<float4*>(o)[q] = float4{y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < kReaderMaxSd; ++k)
+      if (k < A.state_dim) o[k] = (x[k] - mean) * rstd * A.ln_w[k] + A.ln_b[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[A.state_dim + k] = tail[k];
+  }
+  if (A.cnt && A.cnt[row] > 0) A.list[atomicAdd(A.count, 1)] = (int32_t)row;
+}
+
+// ---- the policy step of single rows, exactly as the module computes it (float32) ----------------------------------
+// The few rows of a rollout step that DO have velocity-obstacle rows (13 of 262 144 in the benchmark's world): one
+// workgroup per listed row, thread u = hidden unit u: the (bi)GRU over the row's cnt VO rows (policy_rnn_ac.py:129-168;
+// the recurrent product only from the second step on), direction sum, concat, LayerNorm, both (256, 256) heads stacks,
+// tanh, sample, log-probability, np.round, stores.  Weights as the modules store them, read from L2; no attempt at
+// speed - the list is short by construction (the caller takes the GEMM path when it is not).  The last workgroup to
+// finish resets the list's counter for the next step: no host involvement at all.
+struct PolicyRowsArgs {
+  const float* obs; int64_t obs_ld;
+  const int32_t* cnt; const int32_t* list; int32_t* count; int32_t* done_blocks;
+  int32_t state_dim, in_dim, H, slots;          // 12, 9, reader hidden (<= 256), nm
+  const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];  // [3H][in_dim], [3H][H], [3H], [3H]; [1] = reverse direction or null
+  const float *ln_w, *ln_b; float eps;
+  const float *w1[2], *b1[2], *w2[2], *b2[2], *w3[2], *b3[2];  // actor, critic: [256][D], [256], [256][256], [256], [3|1][256], [3|1]
+  PolicySampleArgs S;
+};
+__global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A) {
+  __shared__ float s_x[kReaderMaxSd + 16 * kReaderMaxIn];
+  __shared__ float s_h[2][256];      // the hidden state of the running direction (double-buffered across steps)
+  __shared__ float s_f[kReaderMaxSd + 256], s_a[2][256], s_b[2][256];
+  __shared__ float s_red[8][4];
+  const int u = threadIdx.x, H = A.H, SD = A.state_dim, IN = A.in_dim, D = SD + H;
+  const int n_rows = *A.count;
+  const SampleConsts SC = sample_consts(A.S);
+  for (int li = blockIdx.x; li < n_rows; li += gridDim.x) {
+    const int64_t row = A.list[li];
+    int n = A.cnt[row];
+    n = n < 1 ? 1 : (n > A.slots ? A.slots : n);
+    __syncthreads();
+    for (int i = u; i < SD + n * IN; i += 256) s_x[i] = A.obs[row * A.obs_ld + i];
+    __syncthreads();
+    float hsum = 0.f;
+    for (int dir = 0; dir < 2; ++dir) {
+      if (!A.w_ih[dir]) break;
+      float h = 0.f;
+      for (int step = 0; step < n; ++step) {
+        const int t = dir ? n - 1 - step : step;
+        float g[3], gh[3];
+        if (u < H) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            float acc = A.b_ih[dir][q * H + u];
+            for (int k = 0; k < IN; ++k) acc += A.w_ih[dir][(size_t)(q * H + u) * IN + k] * s_x[SD + t * IN + k];
+            g[q] = acc;
+            float acc2 = A.b_hh[dir][q * H + u];
+            if (step > 0) {
+              const float* wr = A.w_hh[dir] + (size_t)(q * H + u) * H;
+              const float* hp = s_h[(step - 1) & 1];
+              for (int j = 0; j < H; ++j) acc2 += wr[j] * hp[j];
+            }
+            gh[q] = acc2;
+          }
+          const float rg = 1.0f / (1.0f + __expf(-(g[0] + gh[0])));
+          const float zg = 1.0f / (1.0f + __expf(-(g[1] + gh[1])));
+          const float ng = tanhf(g[2] + rg * gh[2]);
+          h = (1.0f - zg) * ng + zg * h;
+          s_h[step & 1][u] = h;
+        }
+        __syncthreads();
+      }
+      hsum += h;
+    }
+    // LayerNorm over concat(p, hsum)
+    float v = u < H ? hsum : 0.f, q2 = v * v;
+    if (u < SD) { v += s_x[u]; q2 += s_x[u] * s_x[u]; }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) { v += __shfl_xor(v, sh, 64); q2 += __shfl_xor(q2, sh, 64); }
+    if ((u & 63) == 0) { s_red[0][u >> 6] = v; s_red[1][u >> 6] = q2; }
+    __syncthreads();
+    const float tot = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const float tot2 = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    const float mean = tot / (float)D;
+    const float rstd = 1.0f / __builtin_sqrtf(__builtin_fmaxf(tot2 / (float)D - mean * mean, 0.f) + A.eps);
+    if (u < SD) s_f[u] = (s_x[u] - mean) * rstd * A.ln_w[u] + A.ln_b[u];
+    if (u < H) s_f[SD + u] = (hsum - mean) * rstd * A.ln_w[SD + u] + A.ln_b[SD + u];
+    __syncthreads();
+    // the two (256, 256) stacks, thread u = unit u; 16 bytes per load where the row length allows (a wave's lanes sit
+    // a whole weight row apart: every load instruction touches 64 cache lines, so few wide loads beat many narrow ones;
+    // a wave per unit with a shuffle reduction was five times slower - one latency chain per unit)
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      float acc = A.b1[net][u];
+      const float* wr = A.w1[net] + (size_t)u * D;
+      if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(A.w1[net]) & 15) == 0) {
+#pragma unroll 8
+        for (int k = 0; k < D; k += 4) {  // (unrolled: eight weight loads in flight per thread, not one)
+          const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+          acc += w4.x * s_f[k] + w4.y * s_f[k + 1] + w4.z * s_f[k + 2] + w4.w * s_f[k + 3];
+        }
+      } else {
+        for (int k = 0; k < D; ++k) acc += wr[k] * s_f[k];
+      }
+      s_a[net][u] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int net = 0; net < 2; ++net) {
+      float acc = A.b2[net][u];
+      const float* wr = A.w2[net] + (size_t)u * 256;
+      if ((reinterpret_cast<uintptr_t>(A.w2[net]) & 15) == 0) {
+#pragma unroll 8
+        for (int k = 0; k < 256; k += 4) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+          acc += w4.x * s_a[net][k] + w4.y * s_a[net][k + 1] + w4.z * s_a[net][k + 2] + w4.w * s_a[net][k + 3];
+        }
+      } else {
+        for (int k = 0; k < 256; ++k) acc += wr[k] * s_a[net][k];
+      }
+      s_b[net][u] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    float o[4] = {s_b[0][u] * A.w3[0][u], s_b[0][u] * A.w3[0][256 + u], s_b[0][u] * A.w3[0][512 + u], s_b[1][u] * A.w3[1][u]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) o[k] += __shfl_xor(o[k], sh, 64);
+      if ((u & 63) == 0) s_red[4 + k][u >> 6] = o[k];
+    }
+    __syncthreads();
+    if (u == 0) {
+      float z[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] = s_red[4 + k][0] + s_red[4 + k][1] + s_red[4 + k][2] + s_red[4 + k][3];
+      finish_row(A.S, SC, row, z[0] + A.b3[0][0], z[1] + A.b3[0][1], z[2] + A.b3[0][2]);
+      A.S.val[row] = z[3] + A.b3[1][0];
+    }
+  }
+  // the last workgroup out resets the list for the next step
+  __syncthreads();
+  if (u == 0) {
+    __threadfence();
+    if (atomicAdd(A.done_blocks, 1) == (int)gridDim.x - 1) { *A.count = 0; *A.done_blocks = 0; __threadfence(); }
+  }
+}
+
 }  // namespace rvo3d

@@ -82,6 +82,13 @@ class MlpWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3")]
 
 
+class RnnPolicy(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w_ih_f", "w_hh_f", "b_ih_f", "b_hh_f", "w_ih_r", "w_hh_r", "b_ih_r", "b_hh_r",
+                                          "ln_w", "ln_b")] + \
+               [("hidden", C.c_int32), ("in_dim", C.c_int32), ("state_dim", C.c_int32), ("slots", C.c_int32),
+                ("ln_eps", C.c_float), ("reserved", C.c_int32), ("pi", MlpWeights), ("v", MlpWeights)]
+
+
 RVO3D_F32, RVO3D_F64, RVO3D_BF16 = 0, 1, 2
 
 
@@ -95,7 +102,7 @@ class StateView(C.Structure):
 SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
            "rvo3d_step_policy", "rvo3d_policy_sample", "rvo3d_policy_mlp_blob_bytes", "rvo3d_policy_mlp_pack",
-           "rvo3d_policy_mlp_sample", "rvo3d_reader_first_step", "rvo3d_rollout_account", "rvo3d_set_reward_f64",
+           "rvo3d_policy_mlp_sample", "rvo3d_reader_zero_features", "rvo3d_policy_rows", "rvo3d_reader_first_step", "rvo3d_rollout_account", "rvo3d_set_reward_f64",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
            "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_kernel_name", "rvo3d_version", "rvo3d_last_error")
 
@@ -129,6 +136,10 @@ def lib():
     L.rvo3d_policy_mlp_pack.argtypes = [C.POINTER(MlpWeights), C.POINTER(MlpWeights), i32, vp, vp]
     L.rvo3d_policy_mlp_sample.argtypes = [vp, i32, vp, C.c_int64, C.c_int64, vp, i32, i32, i32, vp, C.c_float,
                                           C.c_uint64, C.c_uint64] + [vp] * 6
+    L.rvo3d_reader_zero_features.argtypes = [vp, C.c_int64, C.c_int64, i32, i32, vp, vp, C.c_float, C.c_float, C.c_float,
+                                             vp, C.c_int64, vp, vp, vp, vp]
+    L.rvo3d_policy_rows.argtypes = [C.POINTER(RnnPolicy), vp, C.c_int64, vp, vp, vp, vp, i32, vp, C.c_float, C.c_uint64,
+                                    C.c_uint64, vp, vp, vp, vp]
     L.rvo3d_reader_first_step.argtypes = [C.POINTER(GruReader), vp, C.c_int64, C.c_int64, vp, i32, C.c_int64, vp]
     L.rvo3d_rollout_account.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 8
     L.rvo3d_des_vel.argtypes = [vp, vp, vp]

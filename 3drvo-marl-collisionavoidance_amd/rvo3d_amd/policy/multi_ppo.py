@@ -224,13 +224,19 @@ class multi_ppo:
         """How a rollout step runs on the GPU: "mlp" - config 3's MLP(256, 256) actor-critic in reduced precision:
         the whole policy step (cast, hidden layers, heads, sampling, stores) is ONE kernel on the matrix cores,
         rvo3d_policy_mlp_sample; "heads" - other MLP actor-critics (and float32): library GEMMs up to the last
-        hidden layers, everything from there on in rvo3d_policy_sample; "direct" - any other actor-critic with the reference's surface
+        hidden layers, everything from there on in rvo3d_policy_sample; "rnn0" - the reference's biGRU actor-critic with
+        (256, 256) heads in reduced precision: rows without a velocity-obstacle row (nearly all) through the collapsed
+        first layer, rvo3d_reader_zero_features + rvo3d_policy_mlp_sample, the others through the "heads" / "direct" path
+        on a gathered batch; "direct" - any other actor-critic with the reference's surface
         (`ac.pi._distribution`, `ac.v`, e.g. the biGRU rnn_ac): its own forward gives mu and v, the kernel
         samples / rounds / stores; None - the module path of collect() (CPU, or fused_rollout=False)."""
         if self.device.type != "cuda" or not self.fused_rollout:
             return None
         if self.amp and self.fused_mlp and hasattr(self.ac, "mlp_blob") and self.ac.mlp_blob() is not None:
             return "mlp"
+        if (self.amp and self.fused_mlp and not getattr(self, "_rnn0_dense", False) and hasattr(self.ac, "zero_vo_plan")
+                and self.ac.zero_vo_plan() is not None and self.ac.zero_vo_plan()["rows_net"] is not None):
+            return "rnn0"
         if hasattr(self.ac, "fused_plan"):
             plan = self.ac.fused_plan(torch.bfloat16 if self.amp else torch.float32)
             if plan is not None and plan["hidden"] in ((256, 512, 1024) if self.amp else (128, 256, 512, 1024)):
@@ -312,6 +318,7 @@ class multi_ppo:
         mode = self._fused_mode()
         log_std = self.ac.log_std
         mb = self.ac.mlp_blob() if mode == "mlp" else None  # (once per rollout: the weights do not change inside it)
+        zp = self.ac.zero_vo_plan() if mode == "rnn0" else None
         for t in range(T):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
@@ -321,6 +328,30 @@ class multi_ppo:
                                                      p(buf.cnt[t]), 12, 9, 1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
                                                      ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
                            "rvo3d_policy_mlp_sample")
+                ac["step"] += 1
+            if mode == "rnn0":
+                # rows without a velocity-obstacle row: collapsed first layer (rvo3d_reader_zero_features builds its 20
+                # inputs and lists the rows that do have VO rows) + the MFMA kernel; the listed rows: one workgroup each,
+                # as the modules compute them; no host synchronisation
+                if "feat0" not in ac or ac["feat0"].shape != (E * N, zp["width"]):
+                    ac["feat0"] = torch.empty((E * N, zp["width"]), dtype=torch.float32, device=self.device)
+                    ac["vo_list"] = torch.zeros(E * N, dtype=torch.int32, device=self.device)
+                    ac["vo_count"] = torch.zeros(2, dtype=torch.int32, device=self.device)   # [count, finished workgroups]
+                f0, cnt_t = ac["feat0"], buf.cnt[t]
+                _lib.check(L.rvo3d_reader_zero_features(p(x), x.stride(0), E * N, zp["state_dim"], zp["feat_dim"],
+                                                        p(zp["ln_w"]), p(zp["ln_b"]), zp["sum_h0"], zp["sumsq_h0"],
+                                                        zp["eps"], p(f0), f0.stride(0), p(cnt_t), p(ac["vo_list"]),
+                                                        p(ac["vo_count"]), stream()), "rvo3d_reader_zero_features")
+                _lib.check(L.rvo3d_policy_mlp_sample(p(zp["blob"]), zp["width"], p(f0), f0.stride(0), E * N, None, 0, 0,
+                                                     1 if zp["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
+                                                     ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
+                           "rvo3d_policy_mlp_sample")
+                net = zp["rows_net"]
+                net.slots = env.nm if hasattr(env, "nm") else (env.W - zp["state_dim"]) // 9
+                _lib.check(L.rvo3d_policy_rows(C.byref(net), p(x), x.stride(0), p(cnt_t), p(ac["vo_list"]),
+                                               p(ac["vo_count"]), C.c_void_p(ac["vo_count"].data_ptr() + 4),
+                                               1 if zp["tanh"] else 0, p(log_std), 1.0, self._sample_seed, ac["step"],
+                                               p(act_t), p(logp_t), p(val_t), stream()), "rvo3d_policy_rows")
                 ac["step"] += 1
             if mode == "direct":
                 mu, v = self._mu_v(x, buf.cnt[t].view(E * N))
@@ -376,6 +407,10 @@ class multi_ppo:
                 ac["any_extra"].zero_()
         buf.cut[:T] |= ac["cut"].bool()
         self._cur = (buf.obs[T], buf.cnt[T])
+        if mode == "rnn0":
+            # the one-workgroup-per-row kernel is for short lists: a world where more than 1 row in 500 has VO rows
+            # (~500 rows per step at 64 x 4096: ~0.1 ms of that kernel) goes back to the library-GEMM path
+            self._rnn0_dense = float((buf.cnt[:T] > 0).float().mean()) > 2e-3
         s = ac["sums"].sum(dim=0).tolist()
         return float(s[0] / max(s[1], 1.0))
 

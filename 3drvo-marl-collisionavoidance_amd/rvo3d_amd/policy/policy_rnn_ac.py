@@ -362,6 +362,88 @@ class rnn_ac(nn.Module):  # policy_rnn_ac.py:31-72
             return plan
         return _plan_cached(self, dtype, build)
 
+    def zero_vo_plan(self):
+        """Weights for the rollout's fastest path (multi_ppo._collect_fused, mode "rnn0"): rows WITHOUT a velocity-obstacle
+        row - nearly all of a rollout - all share the GRU's hidden state h0 (zero input from h = 0), so LayerNorm(concat(p,
+        h0)) depends on a row through mean and rstd only and the first MLP layer collapses to a product over
+        state_dim + 3 inputs (include/rvo3d.h, rvo3d_reader_zero_features): the whole policy step of such rows is then
+        rvo3d_reader_zero_features + rvo3d_policy_mlp_sample.  Returns dict(blob, width, sum_h0, sumsq_h0, ln_w, ln_b,
+        eps, feat_dim, tanh), rebuilt when a parameter changed; None when the architecture does not fit (LSTM or separate
+        readers, heads other than ReLU (256, 256) stacks, not on a GPU)."""
+        r = self.pi.rnn_reader
+        if (r is None or r is not self.v.rnn_reader or r.mode not in ("GRU", "biGRU") or r.state_dim > 16
+                or r.hidden_dim > 256 or r.input_dim > 16 or next(self.parameters()).device.type != "cuda"):
+            return None
+        nets = (self.pi.net_out, self.v.v_net)
+        lins = [[m for m in n if isinstance(m, nn.Linear)] for n in nets]
+        acts = [[m for m in n if not isinstance(m, nn.Linear)] for n in nets]
+        D = r.state_dim + r.hidden_dim
+        if (any(len(l) != 3 for l in lins) or [m.out_features for m in lins[0]] != [256, 256, 3]
+                or [m.out_features for m in lins[1]] != [256, 256, 1] or any(l[0].in_features != D for l in lins)
+                or not all(isinstance(m, nn.ReLU) for a in acts for m in a[:-1])
+                or not isinstance(acts[0][-1], (nn.Tanh, nn.Identity)) or not isinstance(acts[1][-1], nn.Identity)
+                or any(m.bias is None for l in lins for m in l)):
+            return None
+        params = list(self.parameters())
+        key = (tuple(p._version for p in params), tuple(p.data_ptr() for p in params))
+        hit = getattr(self, "_zero_plan", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        import ctypes as C
+        from .. import _lib
+        L = _lib.lib()
+        dev = params[0].device
+        sd, width = r.state_dim, r.state_dim + 8
+        bf = torch.bfloat16
+        with torch.no_grad():
+            z = torch.zeros((1, r.input_dim), device=dev)
+            h0 = r._gru_first(z, "")
+            if r.mode == "biGRU":
+                h0 = h0 + r._gru_first(z, "_reverse")
+            h0 = h0.reshape(-1).double()
+            g, bt = r.ln.weight.double(), r.ln.bias.double()
+            keep = []
+            for l in lins:
+                W1, b1 = l[0].weight.double(), l[0].bias.double()
+                Wh = W1[:, sd:]
+                a, b, c = Wh @ (h0 * g[sd:]), Wh @ g[sd:], Wh @ bt[sd:] + b1
+                head = lambda x: x.float().to(bf).float()
+                cols = [W1[:, :sd].float()]
+                for vec, sign in ((a, 1.0), (b, -1.0)):
+                    v = (sign * vec).float()
+                    cols += [head(v)[:, None], (v - head(v))[:, None], head(v)[:, None]]
+                cf = c.float()
+                cols += [head(cf)[:, None], (cf - head(cf))[:, None]]
+                keep += [torch.cat(cols, 1).contiguous(), torch.zeros(256, device=dev),
+                         l[1].weight.detach().float().contiguous(), l[1].bias.detach().float().contiguous(),
+                         l[2].weight.detach().float().contiguous(), l[2].bias.detach().float().contiguous()]
+            blob = hit[1]["blob"] if hit is not None else torch.empty(int(L.rvo3d_policy_mlp_blob_bytes(width)),
+                                                                       dtype=torch.uint8, device=dev)
+            wa = _lib.MlpWeights(*[t.data_ptr() for t in keep[:6]])
+            wb = _lib.MlpWeights(*[t.data_ptr() for t in keep[6:]])
+            with torch.cuda.device(dev):
+                _lib.check(L.rvo3d_policy_mlp_pack(C.byref(wa), C.byref(wb), width, C.c_void_p(blob.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                           "rvo3d_policy_mlp_pack")
+                torch.cuda.current_stream(dev).synchronize()  # (the temporaries above die with this scope)
+            # the modules' own tensors for rvo3d_policy_rows (the rows that do have VO rows): live parameters, no copies
+            gp = lambda n: getattr(r.rnn_net, n).data_ptr()
+            bi = r.mode == "biGRU"
+            rows_net = _lib.RnnPolicy(
+                gp("weight_ih_l0"), gp("weight_hh_l0"), gp("bias_ih_l0"), gp("bias_hh_l0"),
+                gp("weight_ih_l0_reverse") if bi else None, gp("weight_hh_l0_reverse") if bi else None,
+                gp("bias_ih_l0_reverse") if bi else None, gp("bias_hh_l0_reverse") if bi else None,
+                r.ln.weight.data_ptr(), r.ln.bias.data_ptr(), r.hidden_dim, r.input_dim, r.state_dim, 0, float(r.ln.eps), 0,
+                _lib.MlpWeights(*[t.data_ptr() for l in lins[0] for t in (l.weight, l.bias)]),
+                _lib.MlpWeights(*[t.data_ptr() for l in lins[1] for t in (l.weight, l.bias)]))
+            ok_rows = all(t.is_contiguous() and t.dtype == torch.float32 for t in params)
+            out = dict(blob=blob, width=width, sum_h0=float(h0.sum()), sumsq_h0=float((h0 * h0).sum()),
+                       rows_net=rows_net if ok_rows else None,
+                       ln_w=r.ln.weight.detach().float().contiguous(), ln_b=r.ln.bias.detach().float().contiguous(),
+                       eps=float(r.ln.eps), feat_dim=D, state_dim=sd, tanh=isinstance(acts[0][-1], nn.Tanh))
+        self._zero_plan = (key, out)
+        return out
+
     def prepare_input(self, obs, cnt, plan, cache):
         """The reader's features [rows, Kp] as the A operand of the first MLP layer: rvo3d_reader_first_step for every
         row (one GRU cell step per direction from h = 0, direction sum, concat, LayerNorm: exact for rows with at most

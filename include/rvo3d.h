@@ -189,6 +189,41 @@ int rvo3d_policy_mlp_sample(const void *blob, int32_t obs_width, const float *ob
                             const int32_t *vo_count, int32_t state_dim, int32_t row_dim, int32_t tanh_out, const float *log_std, float std_factor, uint64_t seed, uint64_t step,
                             float *act, float *logp, float *val, float *dbg_mu, float *dbg_raw, void *stream);
 
+/* The reader's features (rnn_Reader.obs_rnn + LayerNorm, train/policy/policy_rnn_ac.py:75-127) of rows WITHOUT a
+ * velocity-obstacle row, in collapsed form.  The GRU of such a row sees a zero input from h = 0: its hidden state h0 is
+ * the same for every row, and LayerNorm(concat(p, h0)) depends on the row only through mean and rstd, so a linear
+ * layer W on the features is  W_p f_p + rstd a - (mean rstd) b + c  with a = W_h (h0 g_h), b = W_h g_h, c = W_h b_h + bias
+ * (g, b: the LayerNorm's affine).  out [rows][out_ld >= state_dim + 8] receives per row f_p (state_dim floats), rstd as
+ * bf16 head, head, tail, mean rstd likewise, 1, 1: the inputs of rvo3d_policy_mlp_sample with obs_width = state_dim + 8
+ * and first-layer weights [W_p | a_hi a_lo a_hi | -b_hi -b_lo -b_hi | c_hi c_lo], zero bias (the caller builds them once
+ * per optimizer step: rvo3d_amd.policy.policy_rnn_ac.rnn_ac.zero_vo_plan).  sum_h0 / sumsq_h0: the sums of h0 and h0^2,
+ * feat_dim = state_dim + hidden.  Rows that do have VO rows get wrong values: the caller recomputes those (below). */
+int rvo3d_reader_zero_features(const float *obs, int64_t obs_ld, int64_t rows, int32_t state_dim, int32_t feat_dim,
+                               const float *ln_w, const float *ln_b, float sum_h0, float sumsq_h0, float ln_eps,
+                               float *out, int64_t out_ld, const int32_t *vo_count, int32_t *list, int32_t *count,
+                               void *stream);
+
+/* ... and the rows that DO have velocity-obstacle rows: rvo3d_reader_zero_features, given the env's vo_count, appends
+ * their indices to list [rows] (count [1], zero before the first call), and rvo3d_policy_rows computes the policy step
+ * of every listed row exactly as the modules do, in float32 (rnn_Reader: the (bi)GRU over the row's vo_count rows,
+ * direction sum, concat, LayerNorm - policy_rnn_ac.py:75-168; GaussianActor / Critic stacks state_dim + hidden -> 256
+ * -> 256 -> 3 / 1 - :197-257; sample, log-probability, np.round, stores as rvo3d_policy_sample), one workgroup per row,
+ * overwriting what rvo3d_policy_mlp_sample wrote for it; it resets count for the next step (done_blocks [1]: scratch,
+ * zero before the first call).  No host synchronisation.  Meant for SHORT lists (a rollout of the benchmark's world has
+ * a dozen such rows among 262 144): weights are read as the modules store them, a row costs ~50 us of one workgroup. */
+typedef struct rvo3d_rnn_policy {
+  const float *w_ih_f, *w_hh_f, *b_ih_f, *b_hh_f; /* nn.GRU: [3 hidden][in_dim], [3 hidden][hidden], [3 hidden] x 2 */
+  const float *w_ih_r, *w_hh_r, *b_ih_r, *b_hh_r; /* reverse direction, all NULL for a unidirectional GRU */
+  const float *ln_w, *ln_b;                       /* [state_dim + hidden] */
+  int32_t hidden, in_dim, state_dim, slots;       /* slots = neighbors_num (VO rows per observation) */
+  float ln_eps;
+  int32_t reserved;
+  rvo3d_mlp_weights pi, v;                        /* widths state_dim + hidden -> 256 -> 256 -> 3 / 1 */
+} rvo3d_rnn_policy;
+int rvo3d_policy_rows(const rvo3d_rnn_policy *net, const float *obs, int64_t obs_ld, const int32_t *vo_count,
+                      const int32_t *list, int32_t *count, int32_t *done_blocks, int32_t tanh_out, const float *log_std,
+                      float std_factor, uint64_t seed, uint64_t step, float *act, float *logp, float *val, void *stream);
+
 /* rnn_Reader.obs_rnn (train/policy/policy_rnn_ac.py:75-127) for observations with AT MOST ONE velocity-obstacle row
  * - nearly all of a rollout's -: the (bi)GRU over a one-step sequence from h = 0 (one cell evaluation per direction,
  * no recurrent product), the sum of the two directions, the concatenation with the proprioceptive part and the

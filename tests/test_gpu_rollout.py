@@ -395,8 +395,124 @@ def test_reader_first_step_matches_the_module(hidden, bi, dt):
     assert L.rvo3d_reader_first_step(C.byref(bad), _p(obs), W, rows, _p(feat), 0, ld, None) == -1
 
 
+def test_collapsed_first_layer_of_rows_without_vo_rows():
+    """rvo3d_reader_zero_features + rvo3d_policy_mlp_sample with rnn_ac.zero_vo_plan()'s weights against the module's own
+    float32 forward (biGRU reader, LayerNorm, (256, 256) heads) on rows without a velocity-obstacle row: the GRU state of
+    such rows is a constant, the LayerNorm enters through mean and rstd, the first layer is a product over 12 + 8
+    inputs.  Tolerance: bf16 operands in the three products, as for the MLP policy (3e-2 on mu / v at these weights);
+    the split of rstd, mean rstd and the collapsed columns into bf16 head + tail keeps the collapse itself at 1e-4."""
+    from rvo3d_amd.policy import rnn_ac
+
+    class Space:
+        shape = (3,)
+    torch.manual_seed(11)
+    ac = rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                use_gpu=False, rnn_mode="biGRU").cuda()
+    with torch.no_grad():
+        for p_ in ac.pi.rnn_reader.parameters():
+            p_.add_(torch.randn_like(p_) * 0.2)
+    zp = ac.zero_vo_plan()
+    assert zp is not None and zp["width"] == 20
+    rows, W = 5000, 102
+    obs = torch.zeros((rows, W), device=DEV)
+    obs[:, :12] = torch.randn((rows, 12), device=DEV) * torch.tensor([30., 30, 5, 2, 2, 2, 1, 1, 1, 1, 1, 1], device=DEV)
+    cnt = torch.zeros(rows, dtype=torch.int32, device=DEV)
+    L = _lib.lib()
+    f0 = torch.empty((rows, 20), device=DEV)
+    _lib.check(L.rvo3d_reader_zero_features(_p(obs), W, rows, 12, 268, _p(zp["ln_w"]), _p(zp["ln_b"]), zp["sum_h0"],
+                                            zp["sumsq_h0"], zp["eps"], _p(f0), 20, None, None, None, None),
+               "rvo3d_reader_zero_features")
+    act, logp, val, mu, raw = _mlp_sample(zp["blob"], 20, f0, ac.log_std.detach())
+    with torch.no_grad():
+        d, _ = ac.pi((obs, cnt))
+        v = ac.v((obs, cnt))
+        # the collapse itself, in float64: first-layer pre-activations from the 20 inputs vs from the 268 features
+        feat = ac.pi.rnn_reader.forward_batch(obs, torch.ones(rows, dtype=torch.int64, device=DEV)).double()
+        lin = [m for m in ac.pi.net_out if isinstance(m, torch.nn.Linear)][0]
+        z_full = feat @ lin.weight.double().T + lin.bias.double()
+    assert float((mu - d.mean).abs().max()) < 3e-2 and float((val - v).abs().max()) < 3e-2
+    # the 20 inputs against the module's LayerNorm: f_p, and rstd / mean rstd recombined from head + tail
+    assert float((f0[:, :12].double() - feat[:, :12]).abs().max()) < 1e-4
+    assert bool((f0[:, 18:] == 1).all()) and bool((f0[:, 12] == f0[:, 13]).all())
+    # reconstruct the first layer from the collapsed columns exactly as the kernel's bf16 products see them
+    h0 = (ac.pi.rnn_reader._gru_first(torch.zeros((1, 9), device=DEV), "")
+          + ac.pi.rnn_reader._gru_first(torch.zeros((1, 9), device=DEV), "_reverse")).reshape(-1).double().detach()
+    g, bt = ac.pi.rnn_reader.ln.weight.double().detach(), ac.pi.rnn_reader.ln.bias.double().detach()
+    Wh = lin.weight.double()[:, 12:].detach()
+    a, b, c = Wh @ (h0 * g[12:]), Wh @ g[12:], Wh @ bt[12:] + lin.bias.double().detach()
+    r = (f0[:, 12] + f0[:, 14]).double(); m = (f0[:, 15] + f0[:, 17]).double()
+    z_col = feat[:, :12] @ lin.weight.double()[:, :12].T.detach() + r[:, None] * a[None, :] - m[:, None] * b[None, :] + c[None, :]
+    assert float((z_col - z_full.detach()).abs().max()) < 1e-4 * max(1.0, float(z_full.abs().max()))
+    bad = L.rvo3d_reader_zero_features(_p(obs), W, rows, 12, 268, _p(zp["ln_w"]), _p(zp["ln_b"]), 0.0, 0.0, 1e-5, _p(f0), 19,
+                                       None, None, None, None)
+    assert bad == -1
+    assert L.rvo3d_reader_zero_features(_p(obs), W, rows, 12, 268, _p(zp["ln_w"]), _p(zp["ln_b"]), 0.0, 0.0, 1e-5, _p(f0), 20,
+                                        _p(cnt), None, None, None) == -1     # counts without a list
+
+
+@pytest.mark.parametrize("bi", [True, False])
+def test_policy_rows_matches_the_modules(bi):
+    """rvo3d_policy_rows - the policy step of the rows that DO have velocity-obstacle rows, one workgroup per row,
+    float32 - against the modules' own forward (rnn_Reader's recurrence over 1..nm VO rows, both directions, LayerNorm,
+    actor / critic stacks): mu and v to 1e-4 (summation order), and the list / counter protocol: the rows are found
+    by rvo3d_reader_zero_features from vo_count, every listed row is overwritten, no other row is touched, the
+    counter is back at zero afterwards."""
+    from rvo3d_amd.policy import rnn_ac
+
+    class Space:
+        shape = (3,)
+    torch.manual_seed(5 + bi)
+    ac = rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                use_gpu=False, rnn_mode="biGRU" if bi else "GRU").cuda()
+    with torch.no_grad():
+        for p_ in ac.pi.rnn_reader.parameters():
+            p_.add_(torch.randn_like(p_) * 0.2)
+    zp = ac.zero_vo_plan()
+    rows, nm = 3000, 10
+    W = 12 + 9 * nm
+    g = torch.Generator(device=DEV).manual_seed(3)
+    cnt = torch.zeros(rows, dtype=torch.int32, device=DEV)
+    pick = torch.randperm(rows, device=DEV, generator=g)[:700]
+    cnt[pick] = torch.randint(1, nm + 1, (700,), device=DEV, generator=g, dtype=torch.int32)
+    obs = torch.randn((rows, W), device=DEV, generator=g)
+    obs *= (torch.arange(W, device=DEV)[None, :] < (12 + 9 * cnt.long())[:, None]).float()
+    L = _lib.lib()
+    f0 = torch.empty((rows, 20), device=DEV)
+    lst = torch.zeros(rows, dtype=torch.int32, device=DEV)
+    ctr = torch.zeros(2, dtype=torch.int32, device=DEV)
+    log_std = ac.log_std.detach()
+    act = torch.full((rows, 3), 9.0, device=DEV); logp = torch.full((rows,), 9.0, device=DEV); val = torch.full((rows,), 9.0, device=DEV)
+    for rep in range(2):      # twice: the second call finds the counter reset by the first
+        _lib.check(L.rvo3d_reader_zero_features(_p(obs), W, rows, 12, 268, _p(zp["ln_w"]), _p(zp["ln_b"]), zp["sum_h0"],
+                                                zp["sumsq_h0"], zp["eps"], _p(f0), 20, _p(cnt), _p(lst), _p(ctr), None),
+                   "rvo3d_reader_zero_features")
+        torch.cuda.synchronize()
+        assert int(ctr[0]) == 700 and sorted(lst[:700].tolist()) == sorted(pick.tolist())
+        net = zp["rows_net"]; net.slots = nm
+        _lib.check(L.rvo3d_policy_rows(C.byref(net), _p(obs), W, _p(cnt), _p(lst), _p(ctr), C.c_void_p(ctr.data_ptr() + 4), 1,
+                                       _p(log_std), 1.0, 7, rep, _p(act), _p(logp), _p(val), None), "rvo3d_policy_rows")
+        torch.cuda.synchronize()
+        assert ctr.tolist() == [0, 0]
+    untouched = torch.ones(rows, dtype=torch.bool, device=DEV); untouched[pick] = False
+    assert bool((val[untouched] == 9.0).all()) and bool((act[untouched] == 9.0).all())
+    with torch.no_grad():
+        arg = (obs[pick], cnt[pick])
+        d, _ = ac.pi(arg)
+        v = ac.v(arg)
+    assert float((val[pick] - v).abs().max()) < 1e-4
+    std = torch.clamp(torch.exp(log_std) + 1e-6, 1e-4, 10.0)
+    # the stored action is round(mu + std eps, 2) with the generator's eps for (row, call 1): recover mu from it
+    zero = torch.zeros((rows, 3), device=DEV)
+    _, _, _, _, eps_std = _sample(zero, torch.zeros((rows, 1), device=DEV), None, None, None, None, log_std, rows, 0,
+                                  _lib.RVO3D_F32, step=1)
+    mu_rec = act[pick] - eps_std[pick]
+    assert float((mu_rec - d.mean).abs().max()) < 5.1e-3 + 1e-4      # np.round(a, 2): half a cent
+    lp = torch.distributions.Normal(d.mean, std).log_prob(d.mean + eps_std[pick]).sum(-1)
+    assert float((logp[pick] - lp).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("amp,kind", [(False, "mlp"), (True, "mlp"), (True, "mlp_gemm"), (False, "rnn"), (False, "mlp_small"),
-                                      (False, "rnn256"), (True, "rnn256")])
+                                      (False, "rnn256"), (True, "rnn256"), (True, "rnn256_gemm")])
 def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     """The fused loop (multi_ppo._collect_fused) on 16 drones x 64 envs: (a) a second env stepped with the
     STORED actions reproduces every stored observation, count and reward bit for bit - the buffer holds
@@ -414,7 +530,7 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
 
         class Space:
             shape = (3,)
-        hs, mh = (32, (64, 64)) if kind == "rnn" else (256, (256, 256))
+        hs, mh = (32, (64, 64)) if kind == "rnn" else (256, (256, 256))   # ("rnn256_gemm": library GEMMs, see below)
         ac = rnn_ac(None, Space(), 12, 9, hs, mh, mh, torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
                     use_gpu=False, rnn_mode="biGRU").cuda()
     else:               # (64, 64): a hidden width the heads kernel has no instantiation for -> "direct" as well
@@ -422,9 +538,11 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
     # bf16 + MLP(256, 256): the whole policy step is rvo3d_policy_mlp_sample ("mlp"); "mlp_gemm" keeps the library-GEMM
     # path of the same shape alive (other widths / float32 use it)
     tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=9, train_pi_iters=1, train_v_iters=1, amp=amp, seed=3,
-                   fused_mlp=kind != "mlp_gemm")
-    assert tr._fused_mode() == ("mlp" if (kind == "mlp" and amp) else "heads" if kind in ("mlp", "mlp_gemm", "rnn256")
-                                else "direct")
+                   fused_mlp=kind not in ("mlp_gemm", "rnn256_gemm"))
+    # bf16 + the biGRU actor-critic with (256, 256) heads: "rnn0" - rows without a VO row through the collapsed first
+    # layer, the others (many in this dense little world) through the general path on a gathered batch
+    assert tr._fused_mode() == ("mlp" if (kind == "mlp" and amp) else "rnn0" if (kind == "rnn256" and amp)
+                                else "heads" if kind in ("mlp", "mlp_gemm", "rnn256", "rnn256_gemm") else "direct")
     env.reset(); env.observe()
     mean_ret = tr.collect()
     buf = tr.buf
