@@ -319,6 +319,8 @@ class multi_ppo:
         log_std = self.ac.log_std
         mb = self.ac.mlp_blob() if mode == "mlp" else None  # (once per rollout: the weights do not change inside it)
         zp = self.ac.zero_vo_plan() if mode == "rnn0" else None
+        if mode == "rnn0" and "vo_count" in ac:
+            ac["vo_count"].zero_()  # (the kernels leave it at zero; a rollout that was interrupted half-way may not have)
         for t in range(T):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
