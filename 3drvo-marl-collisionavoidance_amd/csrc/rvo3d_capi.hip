@@ -757,7 +757,9 @@ int rvo3d_reader_zero_features(const float* obs, int64_t obs_ld, int64_t rows, i
     return fail(RVO3D_ERR_INVALID, "vo_count, list and count go together");
   if (state_dim < 1 || state_dim > rvo3d::kReaderMaxSd || feat_dim <= state_dim)
     return fail(RVO3D_ERR_INVALID, "need 1 <= state_dim <= 32 and feat_dim > state_dim");
-  if (rows < 0 || obs_ld < state_dim || out_ld < state_dim + 8) return fail(RVO3D_ERR_INVALID, "rows / row strides too small");
+  // (the kernel reads the state in 16-byte pieces: the last one may take up to three floats beyond state_dim, still inside the row)
+  if (rows < 0 || obs_ld < (state_dim + 3) / 4 * 4 || out_ld < state_dim + 8)
+    return fail(RVO3D_ERR_INVALID, "rows / row strides too small");
   if (rows == 0) return RVO3D_OK;
   rvo3d::ZeroFeatArgs A{obs, obs_ld, rows, state_dim, feat_dim, ln_w, ln_b, sum_h0, sumsq_h0, ln_eps, out, out_ld,
                         vo_count, list, count};
