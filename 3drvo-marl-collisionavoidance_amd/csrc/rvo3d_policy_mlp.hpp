@@ -136,7 +136,10 @@ __device__ __forceinline__ float relu_f32(float x) {
 #define RVO3D_MLP_CLOCK 0
 #endif
 // second-layer k-steps per tile whose fragments stay in LDS; the other 16 - TR are streamed from L2 per wave
-__host__ __device__ constexpr int mlp_tr(int ks1) { return ks1 <= 7 ? 12 : 11; }
+// (as many as fit beside the first layer: all 16 for narrow inputs - nothing streamed -, 12 at config 3's width)
+__host__ __device__ constexpr int mlp_tr(int ks1) {
+  return (157 - 8 * ks1) / 8 >= 16 ? 16 : (157 - 8 * ks1) / 8;
+}
 __host__ __device__ constexpr int mlp_lds_bytes(int ks1) {
   return 8 * ks1 * 1024 + kMlpB2Bytes + kMlpW3Bytes + 8 * mlp_tr(ks1) * 1024;
 }
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
     RVO3D_MLP_STAMP(0)
     u32x4 H1[16];  // H1^T [256][32] as the 16 B fragments of the second product
     f32x16 accs[2];
-    bf16x8 S[NS];  // the streamed fragments of the next second-layer tile
+    bf16x8 S[NS > 0 ? NS : 1];  // the streamed fragments of the next second-layer tile (none when everything is resident)
     // ---- layer 1: H1^T = relu(W1 X^T): one flat stream of fragments out of LDS ----
     // Three straight-line versions, chosen per pass (wave-uniform): every k-step; the first ND_SPARSE k-steps (rows with
     // at most two kept VO rows) plus the bias step; the first k-step (rows without any: nearly all of a rollout) plus
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(64 * NW) policy_mlp_kernel(const PolicyMlpArgs
           bf16x8 a;
           int t;  // the k-step this MFMA covers
           if (v < NS) {
-            a = S[v]; t = TR + v;
+            a = S[v < NS ? v : 0]; t = TR + v;
           } else {
             const int i = m2 * TR + (v - NS);
             a = ring[i % D2]; t = v - NS;
