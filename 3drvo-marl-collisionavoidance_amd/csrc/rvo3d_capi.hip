@@ -239,6 +239,11 @@ int launch_policy_mlp(const rvo3d::PolicyMlpArgs& A, unsigned grid, hipStream_t 
 }
 }  // namespace
 
+// optional noise counter in device memory (rvo3d_rollout_set_step_counter): added to the `step` of every sampling launch,
+// advanced by rvo3d_rollout_account - lets a caller replay a captured launch sequence (a HIP graph) with fresh noise
+#include <atomic>
+namespace { std::atomic<uint64_t*> g_step_dev{nullptr}; }
+
 extern "C" {
 
 int rvo3d_version(void) { return RVO3D_VERSION; }
@@ -645,6 +650,7 @@ int rvo3d_policy_sample(const rvo3d_policy_heads* hd, int64_t rows, float std_fa
   A.hidden = hd->hidden; A.tanh_out = hd->hidden == 0 ? 0 : hd->tanh_out;  // (mu given: already activated)
   A.w_pi = hd->w_pi; A.b_pi = hd->b_pi; A.w_v = hd->w_v; A.b_v = hd->b_v; A.log_std = hd->log_std;
   A.std_factor = std_factor; A.seed = seed; A.step = step; A.rows = rows;
+  A.step_dev = g_step_dev.load();
   A.act = act; A.logp = logp; A.val = val; A.dbg_mu = dbg_mu; A.dbg_raw = dbg_raw;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (hd->hidden == 0) {
@@ -726,6 +732,7 @@ int rvo3d_policy_mlp_sample(const void* blob, int32_t obs_width, const float* ob
     return fail(RVO3D_ERR_INVALID, "vo_count needs 0 <= state_dim <= obs_width and row_dim >= 1");
   A.S = rvo3d::PolicySampleArgs{};
   A.S.tanh_out = tanh_out; A.S.log_std = log_std; A.S.std_factor = std_factor; A.S.seed = seed; A.S.step = step;
+  A.S.step_dev = g_step_dev.load();
   A.S.rows = rows; A.S.act = act; A.S.logp = logp; A.S.val = val; A.S.dbg_mu = dbg_mu; A.S.dbg_raw = dbg_raw;
   // one workgroup per CU, half of them per network; every wave takes 64 rows per trip
   const int64_t nchunks = (rows + 63) / 64;
@@ -799,6 +806,7 @@ int rvo3d_policy_rows(const rvo3d_rnn_policy* net, const float* obs, int64_t obs
   }
   A.S = rvo3d::PolicySampleArgs{};
   A.S.tanh_out = tanh_out; A.S.log_std = log_std; A.S.std_factor = std_factor; A.S.seed = seed; A.S.step = step;
+  A.S.step_dev = g_step_dev.load();
   A.S.act = act; A.S.logp = logp; A.S.val = val;
   hipLaunchKernelGGL(rvo3d::policy_rows_kernel, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), A);
   HIP_TRY(hipGetLastError());
@@ -837,6 +845,13 @@ int rvo3d_reader_first_step(const rvo3d_gru_reader* rd, const float* obs, int64_
   RVO3D_API_END
 }
 
+int rvo3d_rollout_set_step_counter(uint64_t* device_counter) {
+  RVO3D_API_BEGIN
+  g_step_dev.store(device_counter);
+  return RVO3D_OK;
+  RVO3D_API_END
+}
+
 int rvo3d_rollout_account(int32_t E, int32_t N, const float* reward, const uint8_t* done, const uint8_t* finish,
                           int32_t sanitize, int32_t max_ep_len, int32_t epoch_end, float* rew_slot, float* ep_ret,
                           int32_t* ep_len, uint8_t* cut_slot, uint8_t* extra_mask, double* sums, int32_t* any_extra,
@@ -846,7 +861,7 @@ int rvo3d_rollout_account(int32_t E, int32_t N, const float* reward, const uint8
   if (!reward || !done || !finish || !rew_slot || !ep_ret || !ep_len || !cut_slot || !extra_mask || !sums || !any_extra)
     return fail(RVO3D_ERR_INVALID, "null pointer");
   rvo3d::AccountArgs A{E, N, reward, done, finish, sanitize, max_ep_len, epoch_end, rew_slot, ep_ret, ep_len,
-                       cut_slot, extra_mask, sums, any_extra};
+                       cut_slot, extra_mask, sums, any_extra, g_step_dev.load()};
   hipLaunchKernelGGL(rvo3d::rollout_account_kernel, dim3((unsigned)E), dim3((unsigned)align_up((size_t)N, 64)), 0,
                      static_cast<hipStream_t>(stream), A);
   HIP_TRY(hipGetLastError());

@@ -54,6 +54,7 @@ struct PolicySampleArgs {
   const float* log_std;  // [3]     GaussianActor.log_std (policy_rnn_ac.py:198)
   float std_factor;
   uint64_t seed, step;
+  const uint64_t* step_dev;  // optional: a counter in device memory added to `step` (rvo3d_rollout_set_step_counter)
   int64_t rows;
   float* act;            // [rows][3]  np.round(a, 2) in float32, what the buffer stores (multi_ppo.py:197) and the env steps from
   float* logp;           // [rows]     log-probability of the UNROUNDED sample (policy_rnn_ac.py:63-64)
@@ -64,7 +65,7 @@ struct PolicySampleArgs {
 
 // GaussianActor._distribution (policy_rnn_ac.py:217-222): std = clamp(std_factor * exp(log_std) + 1e-6, 1e-4, 10) - the
 // same for every row of a launch: computed once per lane, not once per row
-struct SampleConsts { float sd[3], inv2var[3], log_sd[3]; };
+struct SampleConsts { float sd[3], inv2var[3], log_sd[3]; uint64_t step; };
 __device__ __forceinline__ SampleConsts sample_consts(const PolicySampleArgs& A) {
   SampleConsts C;
 #pragma unroll
@@ -73,6 +74,7 @@ __device__ __forceinline__ SampleConsts sample_consts(const PolicySampleArgs& A)
     sd = sd < 1e-4f ? 1e-4f : (sd > 10.0f ? 10.0f : sd);
     C.sd[k] = sd; C.inv2var[k] = 1.0f / (2.0f * sd * sd); C.log_sd[k] = __logf(sd);
   }
+  C.step = A.step + (A.step_dev ? *A.step_dev : 0);
   return C;
 }
 // tanh from one exp and one reciprocal: 1 - 2 / (e^2x + 1); exact limits at both ends, absolute error < 3e-7
@@ -85,7 +87,7 @@ __device__ __forceinline__ void finish_row(const PolicySampleArgs& A, const Samp
   float mu[3] = {z0, z1, z2};
   if (A.tanh_out) { mu[0] = tanh_fast(z0); mu[1] = tanh_fast(z1); mu[2] = tanh_fast(z2); }
   float eps[3];
-  normal3(A.seed, A.step, (uint64_t)row, eps);
+  normal3(A.seed, C.step, (uint64_t)row, eps);
   float lp = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -249,6 +251,7 @@ struct AccountArgs {
                            //         owns an env's pair: no atomics - 8192 atomic adds per step on two addresses
                            //         took 100 us; the caller sums over the envs when it reads the statistic)
   int32_t* any_extra;      // [1]     |= 1 when extra_mask has a non-zero byte
+  uint64_t* step_dev;      // optional: the noise counter of rvo3d_rollout_set_step_counter, advanced by one per call
 };
 
 __global__ void __launch_bounds__(512) rollout_account_kernel(const AccountArgs A) {
@@ -256,6 +259,7 @@ __global__ void __launch_bounds__(512) rollout_account_kernel(const AccountArgs 
   __shared__ double s_sum[8], s_cnt[8];
   const int e = blockIdx.x, d = threadIdx.x;
   if (d == 0) { s_term = 0; s_extra = 0; }
+  if (e == 0 && d == 0 && A.step_dev) *A.step_dev += 1;  // one rollout step done: the next policy call draws new noise
   __syncthreads();
   double my_sum = 0.0, my_cnt = 0.0;
   if (d < A.N) {

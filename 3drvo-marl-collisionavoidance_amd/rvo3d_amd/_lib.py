@@ -102,7 +102,7 @@ class StateView(C.Structure):
 SYMBOLS = ("rvo3d_create", "rvo3d_destroy", "rvo3d_load_world", "rvo3d_reset",
            "rvo3d_reset_drones", "rvo3d_observe", "rvo3d_step", "rvo3d_step_autoreset",
            "rvo3d_step_policy", "rvo3d_policy_sample", "rvo3d_policy_mlp_blob_bytes", "rvo3d_policy_mlp_pack",
-           "rvo3d_policy_mlp_sample", "rvo3d_reader_zero_features", "rvo3d_policy_rows", "rvo3d_reader_first_step", "rvo3d_rollout_account", "rvo3d_set_reward_f64",
+           "rvo3d_policy_mlp_sample", "rvo3d_reader_zero_features", "rvo3d_policy_rows", "rvo3d_reader_first_step", "rvo3d_rollout_account", "rvo3d_rollout_set_step_counter", "rvo3d_set_reward_f64",
            "rvo3d_des_vel", "rvo3d_rvo_vel", "rvo3d_state_ptrs", "rvo3d_get_state", "rvo3d_set_state",
            "rvo3d_error_flags", "rvo3d_launch_info", "rvo3d_kernel_name", "rvo3d_version", "rvo3d_last_error")
 
@@ -141,6 +141,7 @@ def lib():
     L.rvo3d_policy_rows.argtypes = [C.POINTER(RnnPolicy), vp, C.c_int64, vp, vp, vp, vp, i32, vp, C.c_float, C.c_uint64,
                                     C.c_uint64, vp, vp, vp, vp]
     L.rvo3d_reader_first_step.argtypes = [C.POINTER(GruReader), vp, C.c_int64, C.c_int64, vp, i32, C.c_int64, vp]
+    L.rvo3d_rollout_set_step_counter.argtypes = [vp]
     L.rvo3d_rollout_account.argtypes = [i32, i32, vp, vp, vp, i32, i32, i32] + [vp] * 8
     L.rvo3d_des_vel.argtypes = [vp, vp, vp]
     L.rvo3d_rvo_vel.argtypes = [vp, C.POINTER(C.c_double), C.c_double, vp, vp]

@@ -155,7 +155,7 @@ class multi_ppo:
                  save_result=False, counter=0, test_env=None, lr_decay_epoch=1000,
                  max_update_num=None, mpi=False, figure_save_path=None, minibatch_size=None,
                  dist=None, sanitize_rewards=True, amp=False, reference_order=False, fused_rollout=True,
-                 rollout_chunk=None, tune_gemms=True, tune_update=False, fused_mlp=True, **kwargs):
+                 rollout_chunk=None, tune_gemms=True, tune_update=False, fused_mlp=True, graph_rollout=False, **kwargs):
         np.random.seed(seed)
         self.env, self.ac, self.dist = env, ac_policy, dist
         # The agent order of the reference-order update comes from a generator of its own, seeded like
@@ -168,6 +168,10 @@ class multi_ppo:
         # bf16 rollouts of the MLP(256, 256) actor-critic: the policy step as ONE matrix-core kernel
         # (rvo3d_policy_mlp_sample) instead of cast + three library GEMMs + rvo3d_policy_sample
         self.fused_mlp = bool(fused_mlp)
+        # the fast paths' per-step launches replayed as HIP graphs from the second rollout on (see _collect_fused);
+        # opt-in: measured at 64 x 4096, 0.158 ms per step with and 0.157-0.161 without - the gaps between the dependent
+        # kernels of a graph are what they are between stream launches
+        self.graph_rollout = bool(graph_rollout)
         self.rollout_chunk = rollout_chunk  # rows per policy pass of the fused rollout (None / 0: all at once)
         # the rollout's policy GEMMs ([E*N, 128] x [128, 512], [E*N, 256] x [256, 256], bf16) through PyTorch's
         # TunableOp: the first call of a shape times hipBLASLt's candidate kernels (<= 3 s per shape) and keeps
@@ -321,14 +325,30 @@ class multi_ppo:
         zp = self.ac.zero_vo_plan() if mode == "rnn0" else None
         if mode == "rnn0" and "vo_count" in ac:
             ac["vo_count"].zero_()  # (the kernels leave it at zero; a rollout that was interrupted half-way may not have)
-        for t in range(T):
+        # Graph replay (graph_rollout=True; the MLP and biGRU fast paths): the launches of step t - every argument by value,
+        # every buffer slot at a fixed address - are captured once per slot into a HIP graph and replayed in later
+        # epochs (the loop's wall time exceeds its GPU time by the dispatch gaps between three to five dependent
+        # launches; measured: a graph's kernels keep those gaps - no gain, hence opt-in).  The noise counter then lives in device memory
+        # (rvo3d_rollout_set_step_counter: rvo3d_rollout_account advances it).  Only when no episode can time out
+        # inside the rollout (that check reads the device) and after one eager rollout (allocations, first calls).
+        use_graph = (self.graph_rollout and mode in ("mlp", "rnn0") and T <= self.max_ep_len and not self.rollout_chunk
+                     and getattr(self, "_graph_warm", None) == mode and not getattr(self, "_graph_failed", False))
+        self._graph_warm = mode
+        if use_graph:
+            if getattr(self, "_step_dev", None) is None:
+                self._step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+                self._graphs = {}
+            _lib.check(L.rvo3d_rollout_set_step_counter(p(self._step_dev)), "rvo3d_rollout_set_step_counter")
+        step_arg = lambda: (1 << 32) if (use_graph and not getattr(self, "_graph_failed", False)) else ac["step"]
+
+        def launches(t, epoch_ended):
             x = buf.obs[t].view(E * N, env.W)
             act_t, logp_t, val_t = buf.act[t].view(E * N, 3), buf.logp[t].view(E * N), buf.val[t].view(E * N)
             if mode == "mlp":
                 # (the env's counts: column groups that are zero for all rows of a wave are skipped)
                 _lib.check(L.rvo3d_policy_mlp_sample(p(mb["blob"]), env.W, p(x), x.stride(0), E * N,
                                                      p(buf.cnt[t]), 12, 9, 1 if mb["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
-                                                     ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
+                                                     step_arg(), p(act_t), p(logp_t), p(val_t), None, None, stream()),
                            "rvo3d_policy_mlp_sample")
                 ac["step"] += 1
             if mode == "rnn0":
@@ -346,13 +366,13 @@ class multi_ppo:
                                                         p(ac["vo_count"]), stream()), "rvo3d_reader_zero_features")
                 _lib.check(L.rvo3d_policy_mlp_sample(p(zp["blob"]), zp["width"], p(f0), f0.stride(0), E * N, None, 0, 0,
                                                      1 if zp["tanh"] else 0, p(log_std), 1.0, self._sample_seed,
-                                                     ac["step"], p(act_t), p(logp_t), p(val_t), None, None, stream()),
+                                                     step_arg(), p(act_t), p(logp_t), p(val_t), None, None, stream()),
                            "rvo3d_policy_mlp_sample")
                 net = zp["rows_net"]
                 net.slots = env.nm if hasattr(env, "nm") else (env.W - zp["state_dim"]) // 9
                 _lib.check(L.rvo3d_policy_rows(C.byref(net), p(x), x.stride(0), p(cnt_t), p(ac["vo_list"]),
                                                p(ac["vo_count"]), C.c_void_p(ac["vo_count"].data_ptr() + 4),
-                                               1 if zp["tanh"] else 0, p(log_std), 1.0, self._sample_seed, ac["step"],
+                                               1 if zp["tanh"] else 0, p(log_std), 1.0, self._sample_seed, step_arg(),
                                                p(act_t), p(logp_t), p(val_t), stream()), "rvo3d_policy_rows")
                 ac["step"] += 1
             if mode == "direct":
@@ -390,13 +410,39 @@ class multi_ppo:
                 del hp, hv
             # the env steps from the stored (rounded) action: rounding twice is rounding once
             env.step_policy(buf.act[t], autoreset=True, obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
-            since_full_reset += 1
-            epoch_ended = final_reset and t == T - 1
             _lib.check(L.rvo3d_rollout_account(E, N, p(env.reward), p(env.done), p(env.finish),
                                                1 if self.sanitize_rewards else 0, int(self.max_ep_len),
                                                1 if epoch_ended else 0, p(buf.rew[t]), p(self.ep_ret), p(self.ep_len),
                                                p(ac["cut"][t]), p(ac["extra"]), p(ac["sums"]), p(ac["any_extra"]),
                                                stream()), "rvo3d_rollout_account")
+
+        def one_step(t, epoch_ended):
+            if not use_graph or getattr(self, "_graph_failed", False):
+                return launches(t, epoch_ended)
+            key = (mode, t, bool(epoch_ended), T, buf.obs.data_ptr(), buf.act.data_ptr(), buf.logp.data_ptr(),
+                   buf.val.data_ptr(), buf.rew.data_ptr(), buf.cnt.data_ptr(), ac["cut"].data_ptr(),
+                   (mb or zp)["blob"].data_ptr(), env.obs.data_ptr(), id(env))
+            g = self._graphs.get(key)
+            if g is None:
+                if len(self._graphs) > 4 * T + 8:
+                    self._graphs.clear()  # (buffers were replaced: the old slots' graphs are dead weight)
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        launches(t, epoch_ended)
+                    self._graphs[key] = g
+                except Exception as ex:  # capture is a courtesy of the runtime: without it the loop runs as before
+                    warnings.warn(f"rollout graph capture failed ({type(ex).__name__}: {ex}); continuing without graphs")
+                    self._graph_failed = True
+                    self._graphs.clear()
+                    _lib.check(L.rvo3d_rollout_set_step_counter(None), "rvo3d_rollout_set_step_counter")
+                    return launches(t, epoch_ended)
+            g.replay()
+
+        for t in range(T):
+            epoch_ended = final_reset and t == T - 1
+            one_step(t, epoch_ended)
+            since_full_reset += 1
             buf.ptr += 1
             # only now can an episode have timed out (no episode is longer than the steps since the last
             # full reset): before that the device is not asked (no synchronisation in the loop)
@@ -407,6 +453,8 @@ class multi_ppo:
                 env.reset_drones(ac["extra"])
                 env.observe(obs_out=buf.obs[t + 1], cnt_out=buf.cnt[t + 1])
                 ac["any_extra"].zero_()
+        if use_graph:
+            _lib.check(L.rvo3d_rollout_set_step_counter(None), "rvo3d_rollout_set_step_counter")
         buf.cut[:T] |= ac["cut"].bool()
         self._cur = (buf.obs[T], buf.cnt[T])
         if mode == "rnn0":
@@ -486,6 +534,7 @@ class multi_ppo:
         if os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or "rocprof" in os.environ.get("LD_PRELOAD", ""):
             return out
         T = self.steps_per_epoch
+        graphs, self.graph_rollout = self.graph_rollout, False   # (eager launches: the profiler lists the kernels)
         try:
             from torch.profiler import ProfilerActivity, profile
             self.steps_per_epoch = steps
@@ -504,6 +553,7 @@ class multi_ppo:
             out["profile_error"] = f"{type(ex).__name__}: {ex}"
         finally:
             self.steps_per_epoch = T
+            self.graph_rollout = graphs
             self.buf.ptr = 0
             self.buf.cut.zero_()
         return out

@@ -573,7 +573,7 @@ def rollout_block(env, args):
         tr = multi_ppo(env, ac, train_epoch=0, steps_per_epoch=T, max_ep_len=500, train_pi_iters=2,
                        train_v_iters=2, target_kl=1e9, minibatch_size=E * N, save_freq=10 ** 9, amp=True)
         env.reset(); env.observe()
-        tr.collect(); tr.buf.get()  # warm-up: allocator, hipBLASLt heuristics
+        tr.collect(); tr.buf.get()  # warm-up: allocator, first calls
         torch.cuda.synchronize(); t0 = time.perf_counter()
         tr.collect()
         torch.cuda.synchronize(); t1 = time.perf_counter()

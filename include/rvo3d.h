@@ -224,6 +224,15 @@ int rvo3d_policy_rows(const rvo3d_rnn_policy *net, const float *obs, int64_t obs
                       const int32_t *list, int32_t *count, int32_t *done_blocks, int32_t tanh_out, const float *log_std,
                       float std_factor, uint64_t seed, uint64_t step, float *act, float *logp, float *val, void *stream);
 
+/* Replaying a rollout step as a HIP graph.  The three (MLP policy) or five (biGRU policy) launches of a rollout step take
+ * every argument by value, the noise counter `step` included: a captured graph would draw the same noise on every
+ * replay.  With a device counter registered here (uint64 in device memory, or NULL to unregister; process-wide), every
+ * sampling launch (rvo3d_policy_sample / _mlp_sample / _rows) uses step + *counter, and rvo3d_rollout_account advances
+ * the counter by one per call - so a caller captures [policy, rvo3d_step_policy, rvo3d_rollout_account] once per buffer
+ * slot and replays it every epoch (rvo3d_amd.policy.multi_ppo, graph_rollout=True; measured on MI355X: the same time
+ * per step as the stream launches, 0.158 vs 0.157-0.161 ms). */
+int rvo3d_rollout_set_step_counter(uint64_t *device_counter);
+
 /* rnn_Reader.obs_rnn (train/policy/policy_rnn_ac.py:75-127) for observations with AT MOST ONE velocity-obstacle row
  * - nearly all of a rollout's -: the (bi)GRU over a one-step sequence from h = 0 (one cell evaluation per direction,
  * no recurrent product), the sum of the two directions, the concatenation with the proprioceptive part and the

@@ -594,3 +594,62 @@ def test_fused_rollout_is_a_faithful_rollout(amp, kind):
         tr.buf.ptr = 0
         assert np.isfinite(tr.collect())
     env.close(); env2.close()
+
+
+@pytest.mark.parametrize("kind", ["mlp", "rnn256"])
+def test_graph_replayed_rollouts_are_faithful_and_draw_new_noise(kind):
+    """With multi_ppo(graph_rollout=True) the fast paths replay their per-step launches as HIP graphs from the second rollout on (
+    the noise counter then lives in device memory, rvo3d_rollout_set_step_counter).  Three rollouts - eager, capture +
+    replay, replay: each must be a faithful rollout (a second env stepped with the STORED actions of all three
+    reproduces every stored observation and reward bit for bit), the stored values
+    must be the critic's, and the replays must draw new noise (other actions than the rollout before, although the
+    graph's arguments are the same bytes)."""
+    E, N, T = 32, 16, 12
+    world = synthetic_world(E, N, (12, 12, 6), n_points=3, seed=9)
+    env, env2 = BatchedDroneEnv(world), BatchedDroneEnv(world)
+    torch.manual_seed(1)
+    if kind == "mlp":
+        ac = mlp_ac(env.W).cuda()
+    else:
+        from rvo3d_amd.policy import rnn_ac
+
+        class Space:
+            shape = (3,)
+        ac = rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                    use_gpu=False, rnn_mode="biGRU").cuda()
+    tr = multi_ppo(env, ac, steps_per_epoch=T, max_ep_len=50, train_pi_iters=1, train_v_iters=1, amp=True, seed=3,
+                   graph_rollout=True)
+    env.reset(); env.observe()
+    env2.reset(); o, c = env2.observe()
+    acts = []
+    for rollout in range(3):
+        tr.buf.ptr = 0
+        tr.collect(final_reset=False)
+        if kind == "rnn256":
+            tr._rnn0_dense = False        # (keep the mode under test whatever this little world's density)
+        assert (len(getattr(tr, "_graphs", {})) > 0) == (rollout >= 1) and not getattr(tr, "_graph_failed", False)
+        buf = tr.buf
+        # (env2 follows env through all three rollouts: its last observation is this rollout's first)
+        assert torch.equal(torch.nan_to_num(o, nan=-7.0), torch.nan_to_num(buf.obs[0], nan=-7.0)) and torch.equal(c, buf.cnt[0])
+        for t in range(T):
+            o, c, rew, done, info, fin = env2.step_policy(buf.act[t], autoreset=True)
+            assert torch.equal(torch.nan_to_num(o, nan=-7.0), torch.nan_to_num(buf.obs[t + 1], nan=-7.0)), (rollout, t)
+            assert torch.equal(torch.nan_to_num(buf.rew[t], nan=-7.0),
+                               torch.nan_to_num(torch.nan_to_num(rew, nan=0.0, posinf=0.0, neginf=0.0), nan=-7.0))
+        with torch.no_grad():
+            x = buf.obs[:T].reshape(-1, env.W)
+            arg = (x, buf.cnt[:T].reshape(-1)) if kind == "rnn256" else x
+            v = ac.v(arg)
+            d, _ = ac.pi(arg)
+        assert torch.allclose(buf.val.reshape(-1), v, atol=3e-2, rtol=3e-2)
+        z = (buf.act.reshape(-1, 3) - d.mean) / d.stddev
+        assert abs(float(z.mean())) < 0.03 and abs(float(z.var()) - 1) < 0.08
+        acts.append(buf.act.clone())
+    # new noise in every rollout and in every step of a rollout (the residuals of two steps are not the same numbers)
+    assert not torch.equal(acts[1], acts[2]) and not torch.equal(acts[0], acts[1])
+    with torch.no_grad():
+        res = (tr.buf.act - d.mean.view(T, E, N, 3))
+    assert not torch.allclose(res[0], res[1], atol=1e-3)
+    L = _lib.lib()
+    assert L.rvo3d_rollout_set_step_counter(None) == 0
+    env.close(); env2.close()

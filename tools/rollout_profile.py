@@ -33,7 +33,8 @@ else:
     ac = rnn_ac(None, Space(), 12, 9, 256, (256, 256), (256, 256), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
                 use_gpu=False, rnn_mode="biGRU").cuda()
 tr = multi_ppo(env, ac, steps_per_epoch=args.steps, max_ep_len=500, amp=not args.fp32,
-               fused_rollout=not args.module_path, rollout_chunk=args.chunk)
+               fused_rollout=not args.module_path, rollout_chunk=args.chunk,
+               graph_rollout=False)   # (eager launches: the profiler lists the kernels of a step)
 env.reset(); env.observe()
 tr.collect(final_reset=False); tr.buf.ptr = 0
 torch.cuda.synchronize()
