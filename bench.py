@@ -202,6 +202,10 @@ def parse_args(argv=None):
                     help="skip the `rollout` block (BASELINE config 3 as written: policy forward -> env step -> "
                          "buffer stores, GAE, one PPO update), which runs after the headline timed region")
     ap.add_argument("--rollout-steps", type=int, default=16)
+    ap.add_argument("--rollout-inline", action="store_true",
+                    help="the rollout block in this process (default: a child process, so that nothing that happens "
+                         "in the secondary measurement - a fault, a hang - can cost the headline line)")
+    ap.add_argument("--rollout-only", action="store_true", help=argparse.SUPPRESS)  # the child's mode
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="seconds the launcher (--gpus N > 1 without WORLD_SIZE) waits for its ranks")
     ap.add_argument("--launcher-selftest", action="store_true",
@@ -321,7 +325,39 @@ def main(argv=None):
         return launch_ranks(args, argv)
     if args.launcher_selftest:
         return selftest_rank(args)
+    if args.rollout_only:
+        return rollout_child_main(args)
     return run_rank(args)
+
+
+def rollout_child_main(args):
+    """The child of rollout_in_child: builds its own env of the same shape and prints the rollout record."""
+    from rvo3d_amd import BatchedDroneEnv, synthetic_world
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    wld = synthetic_world(args.envs, args.drones, tuple(args.map), nb=args.buildings, seed=1234)
+    env = BatchedDroneEnv(wld, neighbors_num=args.nm, device=dev, action_decimals=2)
+    print("ROLLOUT_RECORD " + json.dumps(rollout_block(env, args)), flush=True)
+    return 0
+
+
+def rollout_in_child(args):
+    """rollout_block in a child process (started, not exec'ed; at most two processes on the GPU): its record, or an
+    error record - the headline line is printed either way."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--rollout-only", "--envs", str(args.envs), "--drones", str(args.drones),
+           "--nm", str(args.nm), "--buildings", str(args.buildings), "--map", *[str(x) for x in args.map],
+           "--rollout-steps", str(args.rollout_steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("ROLLOUT_RECORD "):
+                return json.loads(line[len("ROLLOUT_RECORD "):])
+        return {"error": f"the rollout child ended with status {r.returncode} and no record", "stderr_tail": r.stderr[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"error": "the rollout child did not finish within 900 s"}
+    except Exception as ex:
+        return {"error": f"{type(ex).__name__}: {ex}"}
 
 
 def run_rank(args):
@@ -479,7 +515,7 @@ def run_rank(args):
 
     rollout = None
     if not args.no_rollout and rank == 0 and world == 1:
-        rollout = rollout_block(env, args)
+        rollout = rollout_in_child(args) if not args.rollout_inline else rollout_block(env, args)
 
     status = 0
     if rank == 0:
