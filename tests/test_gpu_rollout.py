@@ -205,6 +205,29 @@ def test_policy_mlp_sample_matches_torch(W, rows):
     assert torch.allclose(_mlp_sample(_mlp_pack(ac, W), W, x, log_std)[2], val + 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("W", [1, 14, 15, 16, 30, 31, 32, 47, 48, 63, 64, 79, 80, 95, 96, 111, 112, 125])
+def test_policy_mlp_sample_at_every_step_boundary(W):
+    """Observation widths on both sides of every 16-column step boundary (the bias column k = W is the last element of a
+    step at W = 15, 31, ..., the first of a new one at 16, 32, ...; all eight kernel instantiations; the number of
+    second-layer k-steps kept in LDS changes with the width too): against the emulation, with and without counts."""
+    torch.manual_seed(W)
+    rows = 64 * 3 + 37
+    ac = mlp_ac(W).to(DEV)
+    x = torch.randn((rows, W), device=DEV)
+    log_std = torch.tensor([-1.0, -0.5, -1.5], device=DEV)
+    blob = _mlp_pack(ac, W)
+    act, logp, val, mu, raw = _mlp_sample(blob, W, x, log_std)
+    z_emu, v_emu = _mlp_emulation(ac, x)
+    assert float((mu - torch.tanh(z_emu)).abs().max()) < 5e-3 and float((val - v_emu).abs().max()) < 5e-3
+    if W >= 12:   # rows as the env shapes them: 12 floats, 9 per VO row, zeros behind - with their counts: the same bits
+        nmax = (W - 12) // 9
+        cnt = torch.randint(0, nmax + 1, (rows,), device=DEV, dtype=torch.int32)
+        xs = x * (torch.arange(W, device=DEV)[None, :] < (12 + 9 * cnt.long())[:, None]).float()
+        a = _mlp_sample(blob, W, xs, log_std)
+        b = _mlp_sample(blob, W, xs, log_std, cnt=cnt)
+        assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
 @pytest.mark.parametrize("nm", [10, 5, 3])
 def test_policy_mlp_sample_skips_zero_column_groups_exactly(nm):
     """With the env's vo_count the kernel neither loads nor multiplies the 16-float column groups that are zero for all
