@@ -20,8 +20,10 @@ done
 ( cd /tmp && export TMPDIR=/tmp
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cold_trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-rollout --no-cold --cold-all --prewarm 20 --steps 200 > $OUT/cold_trace.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rollout_trace -- python3 $ROOT/tools/bench_rollout.py --amp --steps 16 --no-update --no-tune > $OUT/rollout_trace.log 2>&1 )
-for k in cold rollout; do f=$(find $OUT/${k}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f > $OUT/${k}_kernel_stats.csv; done
-rm -rf $OUT/cold_trace $OUT/rollout_trace
+( cd /tmp && export TMPDIR=/tmp
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rollout_rnn_trace -- python3 $ROOT/tools/bench_rollout.py --amp --steps 16 --no-update --no-tune --policy rnn > $OUT/rollout_rnn_trace.log 2>&1 )
+for k in cold rollout rollout_rnn; do f=$(find $OUT/${k}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -16 $f > $OUT/${k}_kernel_stats.csv; done
+rm -rf $OUT/cold_trace $OUT/rollout_trace $OUT/rollout_rnn_trace
 bash tools/bench_all.sh $R > /dev/null 2>&1; cp gpurun_out/bench_all_$R.txt $OUT/bench_all_shapes.txt
 python bench.py > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
 python tools/bench_rollout.py --amp --steps 16 > $OUT/rollout_bench.json 2>/dev/null
