@@ -100,6 +100,26 @@ def _plan_cached(module, dtype, build):
     return plan
 
 
+def collapsed_first_layer(reader, lin, h0=None):
+    """The first linear layer behind the reader, for rows WITHOUT a velocity-obstacle row, as a function of the row's
+    state_dim proprioceptive floats p alone (float64): with h0 the GRU's hidden state for a zero input from h = 0 (the
+    same for every such row; both directions summed), mean / rstd the LayerNorm statistics of concat(p, h0) and g, bt
+    the LayerNorm's affine,  lin(LayerNorm(concat(p, h0))) = W_p f_p + rstd a - (mean rstd) b + c  with
+    f_p = (p - mean) rstd g_p + bt_p,  a = W_h (h0 g_h),  b = W_h g_h,  c = W_h bt_h + bias.  Returns (W_p, a, b, c)."""
+    sd = reader.state_dim
+    with torch.no_grad():
+        if h0 is None:
+            z = torch.zeros((1, reader.input_dim), device=lin.weight.device)
+            h0 = reader._gru_first(z, "")
+            if reader.mode == "biGRU":
+                h0 = h0 + reader._gru_first(z, "_reverse")
+            h0 = h0.reshape(-1).double()
+        g, bt = reader.ln.weight.double(), reader.ln.bias.double()
+        W1, b1 = lin.weight.double(), lin.bias.double()
+        Wh = W1[:, sd:]
+        return W1[:, :sd], Wh @ (h0 * g[sd:]), Wh @ g[sd:], Wh @ bt[sd:] + b1
+
+
 class _SplitKLinearFn(torch.autograd.Function):
     """y = x W^T + b whose weight gradient is computed as S partial products summed afterwards.  The update's weight
     gradients are [out, rows] x [rows, in] products with rows = 262 144 and 256 x 256 (or 3 x 256) results: as ONE GEMM
@@ -401,14 +421,11 @@ class rnn_ac(nn.Module):  # policy_rnn_ac.py:31-72
             if r.mode == "biGRU":
                 h0 = h0 + r._gru_first(z, "_reverse")
             h0 = h0.reshape(-1).double()
-            g, bt = r.ln.weight.double(), r.ln.bias.double()
             keep = []
             for l in lins:
-                W1, b1 = l[0].weight.double(), l[0].bias.double()
-                Wh = W1[:, sd:]
-                a, b, c = Wh @ (h0 * g[sd:]), Wh @ g[sd:], Wh @ bt[sd:] + b1
+                Wp, a, b, c = collapsed_first_layer(r, l[0], h0)
                 head = lambda x: x.float().to(bf).float()
-                cols = [W1[:, :sd].float()]
+                cols = [Wp.float()]
                 for vec, sign in ((a, 1.0), (b, -1.0)):
                     v = (sign * vec).float()
                     cols += [head(v)[:, None], (v - head(v))[:, None], head(v)[:, None]]

@@ -469,3 +469,37 @@ def test_reader_one_step_fast_path_equals_the_masked_recurrence():
         assert torch.equal(got[: B // 2], want[: B // 2])            # one-step rows: bit for bit
         assert torch.allclose(got, want, atol=1e-6)
         assert torch.equal(r.forward_batch(obs[: B // 2], lens[: B // 2]), want[: B // 2])  # a batch without long rows
+
+
+@pytest.mark.parametrize("mode", ["biGRU", "GRU"])
+def test_collapsed_first_layer_is_the_reader_plus_layer_norm_plus_linear(mode):
+    """policy_rnn_ac.collapsed_first_layer (host side of the rollout's "rnn0" mode): for rows without a velocity-obstacle
+    row the GRU state is a constant and the first MLP layer is W_p f_p + rstd a - (mean rstd) b + c.  In float64 on the
+    CPU against the module's own reader + LayerNorm + Linear: equal to 1e-5 of the pre-activations (the module is float32)."""
+    from rvo3d_amd.policy.policy_rnn_ac import collapsed_first_layer
+    torch.manual_seed(4)
+    ac = rnn_ac(None, _Space(), 12, 9, 32, (64, 64), (64, 64), torch.nn.ReLU, torch.nn.Tanh, torch.nn.Identity,
+                use_gpu=False, rnn_mode=mode)
+    with torch.no_grad():
+        for p_ in ac.pi.rnn_reader.parameters():
+            p_.add_(torch.randn_like(p_) * 0.3)
+    r = ac.pi.rnn_reader
+    rows, W = 500, 12 + 9 * 4
+    obs = torch.zeros((rows, W))
+    obs[:, :12] = torch.randn((rows, 12)) * torch.tensor([30., 30, 5, 2, 2, 2, 1, 1, 1, 1, 1, 1])
+    for net in (ac.pi.net_out, ac.v.v_net):
+        lin = [m for m in net if isinstance(m, torch.nn.Linear)][0]
+        Wp, a, b, c = collapsed_first_layer(r, lin)
+        with torch.no_grad():
+            feat = r.forward_batch(obs, torch.ones(rows, dtype=torch.int64))
+            want = lin(feat).double()
+            h0 = r._gru_first(torch.zeros((1, 9)), "")
+            if mode == "biGRU":
+                h0 = h0 + r._gru_first(torch.zeros((1, 9)), "_reverse")
+            x = torch.cat([obs[:, :12].double(), h0.double().expand(rows, -1)], 1)
+            mean = x.mean(1, keepdim=True)
+            rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + r.ln.eps)
+            f_p = (obs[:, :12].double() - mean) * rstd * r.ln.weight.double()[:12] + r.ln.bias.double()[:12]
+            got = f_p @ Wp.T + rstd * a[None, :] - (mean * rstd) * b[None, :] + c[None, :]
+        assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    assert ac.zero_vo_plan() is None      # (the packed plan itself is a GPU matter: None on the CPU, the rollout takes another path)
