@@ -552,8 +552,8 @@ __global__ void __launch_bounds__(256) reader_zero_features_kernel(const ZeroFea
 }
 
 // ---- the policy step of single rows, exactly as the module computes it (float32) ----------------------------------
-// The few rows of a rollout step that DO have velocity-obstacle rows (13 of 262 144 in the benchmark's world): one
-// workgroup per listed row, thread u = hidden unit u: the (bi)GRU over the row's cnt VO rows (policy_rnn_ac.py:129-168;
+// The few rows of a rollout step that DO have velocity-obstacle rows (13 of 262 144 in the benchmark's world): two
+// workgroups per listed row (one per network), thread u = hidden unit u: the (bi)GRU over the row's cnt VO rows (policy_rnn_ac.py:129-168;
 // the recurrent product only from the second step on), direction sum, concat, LayerNorm, both (256, 256) heads stacks,
 // tanh, sample, log-probability, np.round, stores.  Weights as the modules store them, read from L2; no attempt at
 // speed - the list is short by construction (the caller takes the GEMM path when it is not).  The last workgroup to
@@ -575,7 +575,10 @@ __global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A
   const int u = threadIdx.x, H = A.H, SD = A.state_dim, IN = A.in_dim, D = SD + H;
   const int n_rows = *A.count;
   const SampleConsts SC = sample_consts(A.S);
-  for (int li = blockIdx.x; li < n_rows; li += gridDim.x) {
+  // two workgroups per listed row, one per network (both compute the reader's features - that part is short): the
+  // row's latency chain is as long as ONE stack's weight reads, not two
+  for (int wi = blockIdx.x; wi < 2 * n_rows; wi += gridDim.x) {
+    const int li = wi >> 1, my_net = wi & 1;
     const int64_t row = A.list[li];
     int n = A.cnt[row];
     n = n < 1 ? 1 : (n > A.slots ? A.slots : n);
@@ -630,8 +633,8 @@ __global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A
     // the two (256, 256) stacks, thread u = unit u; 16 bytes per load where the row length allows (a wave's lanes sit
     // a whole weight row apart: every load instruction touches 64 cache lines, so few wide loads beat many narrow ones;
     // a wave per unit with a shuffle reduction was five times slower - one latency chain per unit)
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
+    {
+      const int net = my_net;
       float acc = A.b1[net][u];
       const float* wr = A.w1[net] + (size_t)u * D;
       if ((D & 3) == 0 && (reinterpret_cast<uintptr_t>(A.w1[net]) & 15) == 0) {
@@ -646,8 +649,8 @@ __global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A
       s_a[net][u] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
-#pragma unroll
-    for (int net = 0; net < 2; ++net) {
+    {
+      const int net = my_net;
       float acc = A.b2[net][u];
       const float* wr = A.w2[net] + (size_t)u * 256;
       if ((reinterpret_cast<uintptr_t>(A.w2[net]) & 15) == 0) {
@@ -662,7 +665,9 @@ __global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A
       s_b[net][u] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
-    float o[4] = {s_b[0][u] * A.w3[0][u], s_b[0][u] * A.w3[0][256 + u], s_b[0][u] * A.w3[0][512 + u], s_b[1][u] * A.w3[1][u]};
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (my_net == 0) { o[0] = s_b[0][u] * A.w3[0][u]; o[1] = s_b[0][u] * A.w3[0][256 + u]; o[2] = s_b[0][u] * A.w3[0][512 + u]; }
+    else o[3] = s_b[1][u] * A.w3[1][u];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -674,8 +679,8 @@ __global__ void __launch_bounds__(256) policy_rows_kernel(const PolicyRowsArgs A
       float z[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) z[k] = s_red[4 + k][0] + s_red[4 + k][1] + s_red[4 + k][2] + s_red[4 + k][3];
-      finish_row(A.S, SC, row, z[0] + A.b3[0][0], z[1] + A.b3[0][1], z[2] + A.b3[0][2]);
-      A.S.val[row] = z[3] + A.b3[1][0];
+      if (my_net == 0) finish_row(A.S, SC, row, z[0] + A.b3[0][0], z[1] + A.b3[0][1], z[2] + A.b3[0][2]);
+      else A.S.val[row] = z[3] + A.b3[1][0];
     }
   }
   // the last workgroup out resets the list for the next step

@@ -207,10 +207,11 @@ int rvo3d_reader_zero_features(const float *obs, int64_t obs_ld, int64_t rows, i
  * their indices to list [rows] (count [1], zero before the first call), and rvo3d_policy_rows computes the policy step
  * of every listed row exactly as the modules do, in float32 (rnn_Reader: the (bi)GRU over the row's vo_count rows,
  * direction sum, concat, LayerNorm - policy_rnn_ac.py:75-168; GaussianActor / Critic stacks state_dim + hidden -> 256
- * -> 256 -> 3 / 1 - :197-257; sample, log-probability, np.round, stores as rvo3d_policy_sample), one workgroup per row,
+ * -> 256 -> 3 / 1 - :197-257; sample, log-probability, np.round, stores as rvo3d_policy_sample), two workgroups per row
+ * (one per network),
  * overwriting what rvo3d_policy_mlp_sample wrote for it; it resets count for the next step (done_blocks [1]: scratch,
  * zero before the first call).  No host synchronisation.  Meant for SHORT lists (a rollout of the benchmark's world has
- * a dozen such rows among 262 144): weights are read as the modules store them, a row costs ~50 us of one workgroup. */
+ * a dozen such rows among 262 144): weights are read as the modules store them, a row is a latency chain of ~35 us. */
 typedef struct rvo3d_rnn_policy {
   const float *w_ih_f, *w_hh_f, *b_ih_f, *b_hh_f; /* nn.GRU: [3 hidden][in_dim], [3 hidden][hidden], [3 hidden] x 2 */
   const float *w_ih_r, *w_hh_r, *b_ih_r, *b_hh_r; /* reverse direction, all NULL for a unidirectional GRU */
