@@ -594,6 +594,50 @@ def run_rank(args):
     return status
 
 
+def policy_kernel_roofline(tr, env):
+    """rvo3d_policy_mlp_sample (csrc/rvo3d_policy_mlp.hpp) on the rollout buffer's first slot, as the loop calls it (the
+    env's rows with their vo_count: zero column groups skipped) and on dense random rows of the same shape.  Bound:
+    MFMA.  Algorithmic flops = 2 x (W x 256 + 256 x 256 + 256 x out) per row and network (out = 3 / 1) - what the two
+    MLPs need, not what the kernel issues (padded k-steps, 32-row head tiles)."""
+    import ctypes as C
+    from rvo3d_amd import _lib
+    if tr._fused_mode() != "mlp":
+        return None
+    L = _lib.lib()
+    E, N, W = env.E, env.N, env.W
+    B = E * N
+    mb = tr.ac.mlp_blob()
+    dev = env.device
+    act = torch.empty((B, 3), device=dev); logp = torch.empty(B, device=dev); val = torch.empty(B, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def timed(x, cnt):
+        call = lambda i: _lib.check(L.rvo3d_policy_mlp_sample(p(mb["blob"]), W, p(x), x.stride(0), B, cnt, 12, 9,
+                                                              1 if mb["tanh"] else 0, p(tr.ac.log_std), 1.0, 1, i, p(act),
+                                                              p(logp), p(val), None, None, st), "rvo3d_policy_mlp_sample")
+        for i in range(3):
+            call(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(20):
+            call(i)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 20 * 1e-3
+    x_env, c_env = tr.buf.obs[0].view(B, W), tr.buf.cnt[0]
+    t_env = timed(x_env, p(c_env))
+    t_dense = timed(torch.randn((B, W), device=dev), None)
+    flop = 2.0 * B * ((W * 256 + 256 * 256 + 256 * 3) + (W * 256 + 256 * 256 + 256 * 1))
+    peak = 2500.0
+    return {"kernel": f"rvo3d::policy_mlp_kernel<{(W + 16) // 16}, 8>", "bound": "mfma", "unit": "TFLOP/s", "peak": peak,
+            "algorithmic_gflop_per_launch": round(flop / 1e9, 2),
+            "rollout_rows": {"kernel_ms": round(t_env * 1e3, 4), "achieved": round(flop / t_env / 1e12, 1),
+                             "frac": round(flop / t_env / 1e12 / peak, 4),
+                             "rows_without_vo_rows": round(float((c_env == 0).float().mean()), 5)},
+            "dense_random_rows": {"kernel_ms": round(t_dense * 1e3, 4), "achieved": round(flop / t_dense / 1e12, 1),
+                                  "frac": round(flop / t_dense / 1e12 / peak, 4)}}
+
+
 def rollout_block(env, args):
     """BASELINE config 3 AS WRITTEN - "full MA-PPO rollout + update, MLP(256,256) policy" - measured
     after the headline region, on the same env: T rollout steps of the trainer's own loop
@@ -632,6 +676,10 @@ def rollout_block(env, args):
                "update_first_call_s": round(t2b - t2, 4),
                "update_samples_per_s": round(E * N * T * 4 / (t3 - t2b), 1)}
         rec.update(tr.rollout_profile())  # env_kernel_us, launches_per_step (None when not measurable)
+        try:  # the policy step's own kernel against the matrix-core roofline, HIP events around 20 launches
+            rec["policy_kernel"] = policy_kernel_roofline(tr, env)
+        except Exception as ex:
+            rec["policy_kernel"] = {"error": f"{type(ex).__name__}: {ex}"}
         # the reference's own architecture (biGRU reader 9 -> 256, LayerNorm(268), actor / critic 268-256-256;
         # train/policy/policy_rnn_ac.py:31-257) through the same loop: rollout only, 8 steps
         try:
